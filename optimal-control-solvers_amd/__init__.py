@@ -1,0 +1,11 @@
+"""optimal-control-solvers_amd: MI355X-native batched RK4 state / discrete-adjoint /
+forward-backward-sweep kernels behind the OCProblem / Integrator / Control plugin
+surface of DrDanRyan/Optimal-Control-Solvers.
+
+The directory name is not a Python identifier; load it with
+`__graft_entry__.load_package()` (registers it as module `ocs_amd`).
+"""
+from . import _lib  # noqa: F401  fails loudly when libocs.so is missing
+from ._lib import OcsError  # noqa: F401
+from .problem import OCProblem, TestOCProblem, LogisticProblem  # noqa: F401
+from .integrator import Integrator, RK4Integrator  # noqa: F401

@@ -1,0 +1,83 @@
+"""ctypes binding of libocs.so (the C-ABI declared in include/ocs.h).
+
+There is no CPU fallback: if the shared library has not been built the import fails, and
+every compute call fails with OCS_ERR_NO_DEVICE when no MI355X is visible.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import torch  # noqa: F401  (first: makes torch's libamdhip64.so.7 the process-wide HIP runtime)
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libocs.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ocs.h")
+
+dp = C.POINTER(C.c_double)
+ip = C.POINTER(C.c_int)
+vp = C.c_void_p
+
+
+class OcsError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__(f"libocs error {code}: {msg}")
+        self.code = code
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback.")
+    return C.CDLL(LIB_PATH)
+
+
+lib = _load()
+
+_SIG = {
+    # name: (restype, argtypes)
+    "ocs_version": (C.c_char_p, []),
+    "ocs_last_error": (C.c_char_p, []),
+    "ocs_device_count": (C.c_int, [ip]),
+    "ocs_set_device": (C.c_int, [C.c_int]),
+    "ocs_synchronize": (C.c_int, []),
+    "ocs_problem_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]),
+    "ocs_problem_destroy": (C.c_int, [vp]),
+    "ocs_problem_dims": (C.c_int, [vp, ip, ip]),
+    "ocs_problem_set_batch_params": (C.c_int, [vp, C.c_int, ip, C.c_int, dp]),
+    "ocs_problem_F": (C.c_int, [vp, C.c_int, dp, dp, dp, dp]),
+    "ocs_problem_dFdx_times_vec": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp]),
+    "ocs_problem_dFdu_times_vec": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp]),
+    "ocs_rk4_create": (C.c_int, [C.POINTER(vp), dp, C.c_int]),
+    "ocs_integrator_destroy": (C.c_int, [vp]),
+    "ocs_integrator_nsteps": (C.c_int, [vp, ip]),
+    "ocs_integrator_t": (C.c_int, [vp, dp]),
+    "ocs_integrator_h": (C.c_int, [vp, dp]),
+    "ocs_compute_states": (C.c_int, [vp, vp, C.c_int, dp, dp, dp, dp]),
+    "ocs_compute_adjoints": (C.c_int, [vp, vp, C.c_int, dp, dp, dp, dp]),
+    "ocs_compute_states_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ocs_compute_adjoints_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ocs_to_batch_minor_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+    "ocs_to_traj_major_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
+}
+
+for _name, (_res, _args) in _SIG.items():
+    _fn = getattr(lib, _name)
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+
+def declared_symbols():
+    """Every function include/ocs.h declares (used by the export test)."""
+    with open(HEADER_PATH) as f:
+        src = re.sub(r"/\*.*?\*/", "", f.read(), flags=re.S)
+    return sorted(set(re.findall(r"\b(ocs_[A-Za-z0-9_]+)\s*\(", src)))
+
+
+def check(rc):
+    """Negative status -> exception; positive (numerical condition) is returned to the caller."""
+    if rc < 0:
+        raise OcsError(rc, lib.ocs_last_error().decode())
+    return rc

@@ -1,0 +1,53 @@
+// ocs_internal.hpp -- launcher interface between the C-ABI layer (ocs_api.cpp) and the
+// gfx950 kernels (ocs_kernels.hip).  Not part of the public boundary.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+
+namespace ocs {
+
+// Which device functor a problem handle resolves to.
+enum class Functor : int { Logistic = 1 };
+
+struct ProblemDesc {
+  Functor functor;
+  int nS, nC;
+  int npar;
+  const double* ps;   // device: shared parameter block [npar]
+  const double* pb;   // device: per-trajectory overrides [npar][batch] or nullptr
+  unsigned pmask;     // bit k set -> parameter k is read from pb
+  const double* lb;   // device: control lower bounds [nC]
+  const double* ub;   // device: control upper bounds [nC]
+};
+
+struct GridDesc {
+  int N;              // nSTEPS
+  const double* HT;   // device: [N][4] = {h, h/2, h/6, h/3} (host IEEE divisions, RK4Integrator.m:40,50,73,77)
+  const double* T;    // device: [2N+1] grid times (obj.t)
+  double* TC;         // device: [2N+1][NTC] time coefficients of the bound problem (F side)
+  double* TU;         // device: [2N+1][NTU] time coefficients of its ControlChar
+};
+
+// Device-native layouts (batch-minor): x0 [nS][B], u [2N+1][nC][B], x [N+1][nAug][B],
+// lam [N+1][nAug][B], dJdu [2N+1][nC][B], J [B], lamT [nAug][B].
+int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s);
+int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
+                   double* x, double* J, hipStream_t s);
+int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                    const double* lamT, double* lam, double* dJdu, hipStream_t s);
+// which: 0 F, 1 dFdx_times_vec, 2 dFdu_times_vec; column-major device arrays with k columns.
+int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
+                const double* v, double* out, hipStream_t s);
+// layout helpers; per = doubles per trajectory
+int launch_to_batch_minor(const double* src, double* dst, int per, int batch, hipStream_t s);
+int launch_to_traj_major(const double* src, double* dst, int per, int batch, hipStream_t s);
+// number of non-finite entries of v[0..n) is added to *count (device int)
+int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s);
+
+// registry queries (host)
+bool functor_supported(Functor f, int nS, int nC);
+int functor_ntc(Functor f, int nS);
+int functor_ntu(Functor f, int nS);
+unsigned functor_tc_param_mask(Functor f, int nS);
+
+}  // namespace ocs

@@ -1,0 +1,521 @@
+// ocs_kernels.hip -- gfx950 (MI355X) kernels for the batched RK4 state pass and its exact
+// discrete adjoint.  fp64 throughout.
+//
+// Mapping ("L", lane-per-trajectory): one lane integrates one trajectory; a 64-lane wave
+// (= one workgroup) owns 64 consecutive trajectories.  All per-step quantities that do not
+// depend on the trajectory (step sizes, time coefficients) are wave-uniform and come from
+// scalar loads.  Arrays are batch-minor ([time][row][batch]) so every vector load/store of a
+// wave is one contiguous 512-B segment: coalescing needs no LDS staging in this mapping.
+// The time recursion is serial, so at small batch the passes are bound by fp64 issue on one
+// wave per SIMD, not by HBM; control samples and checkpoints are
+// software-prefetched CH steps ahead in registers so that HBM latency stays off the chain.
+//
+// Reference semantics: Integrator/RK4Integrator.m:28-56 (compute_states), :59-94
+// (compute_adjoints), :97-121 (compute_dJdu).  The reference caches all four stage states
+// (xK); here only y_i is checkpointed and Y2..Y4 are recomputed in the adjoint pass (same
+// arithmetic, deterministic => same values), which cuts checkpoint traffic 4x.
+#include "ocs_internal.hpp"
+#include "ocs_problems.hpp"
+
+namespace ocs {
+
+#define OCS_INLINE __attribute__((always_inline))
+
+static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+// Wave-uniform read-only tables (step sizes, time coefficients, shared parameters) are read
+// through the constant address space so the backend emits scalar (s_load) instead of
+// per-lane vector loads: `__restrict__` on struct members does not reach alias analysis.
+typedef const double __attribute__((address_space(4))) * uniform_ptr;
+__device__ static inline uniform_ptr as_uniform(const double* p) { return (uniform_ptr)p; }
+
+// ---------------------------------------------------------------------------------------
+// time-coefficient table
+// ---------------------------------------------------------------------------------------
+template <class P>
+__global__ void k_tcoef(int nT, const double* __restrict__ T, const double* __restrict__ ps,
+                        double* __restrict__ TC, double* __restrict__ TU) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= nT) return;
+  double tc[P::NTC], tu[P::NTU];
+  P::tcoef(T[j], ps, tc, tu);
+#pragma unroll
+  for (int k = 0; k < P::NTC; ++k) TC[(size_t)j * P::NTC + k] = tc[k];
+  if (TU) {
+#pragma unroll
+    for (int k = 0; k < P::NTU; ++k) TU[(size_t)j * P::NTU + k] = tu[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// forward pass: [x, J] = compute_states(obj, prob, x0, u)      RK4Integrator.m:28-56
+// ---------------------------------------------------------------------------------------
+struct FwdArgs {
+  int N, batch;
+  const double* __restrict__ HT;
+  const double* __restrict__ TC;
+  const double* __restrict__ ps;
+  const double* __restrict__ pb;
+  unsigned pmask;
+  const double* __restrict__ x0;
+  const double* __restrict__ u;
+  double* __restrict__ x;
+  double* __restrict__ J;
+};
+
+template <class P, int CH, bool OUT_X>
+__global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
+  constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC;
+  const int b0 = blockIdx.x * 64 + threadIdx.x;
+  const bool act = b0 < a.batch;
+  const int b = act ? b0 : a.batch - 1;  // clamp: idle lanes replay the last trajectory, stores masked
+  const size_t B = (size_t)a.batch;
+  const int N = a.N;
+
+  const uniform_ptr HT = as_uniform(a.HT), TC = as_uniform(a.TC), PS = as_uniform(a.ps);
+  const typename P::Par p = P::load([&](int k) OCS_INLINE {
+    return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+  });
+
+  double y[NS], yc = 0.0;  // xK(:,1,1) = [x0; 0]   :33
+#pragma unroll
+  for (int k = 0; k < NS; ++k) y[k] = a.x0[(size_t)k * B + b];
+  double* xo = a.x + b;
+  if (OUT_X && act) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) xo[(size_t)k * B] = y[k];
+    xo[(size_t)NS * B] = 0.0;
+  }
+
+  const double* up = a.u + b;  // u(:,j) of this trajectory at up[(j*NC + c)*B]
+  double uprev[NC];
+#pragma unroll
+  for (int c = 0; c < NC; ++c) uprev[c] = up[(size_t)c * B];
+
+  // one RK4 step i (0-based), controls at grid points 2i (uA), 2i+1 (uM), 2i+2 (uB)   :36-51
+  auto step = [&](int i, const double* uA, const double* uM, const double* uB) OCS_INLINE {
+    const double h = HT[4 * i], hh = HT[4 * i + 1], h6 = HT[4 * i + 2];
+    double tcA[NTC], tcM[NTC], tcB[NTC];
+#pragma unroll
+    for (int k = 0; k < NTC; ++k) {
+      tcA[k] = TC[(size_t)(2 * i) * NTC + k];
+      tcM[k] = TC[(size_t)(2 * i + 1) * NTC + k];
+      tcB[k] = TC[(size_t)(2 * i + 2) * NTC + k];
+    }
+    double F1[NS + 1], F2[NS + 1], F3[NS + 1], F4[NS + 1], Y[NS];
+    P::F(tcA, y, uA, p, F1);                                              // :39
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Y[k] = __builtin_fma(hh, F1[k], y[k]);   // :40
+    P::F(tcM, Y, uM, p, F2);                                              // :42
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Y[k] = __builtin_fma(hh, F2[k], y[k]);   // :43
+    P::F(tcM, Y, uM, p, F3);                                              // :45
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Y[k] = __builtin_fma(h, F3[k], y[k]);    // :46
+    P::F(tcB, Y, uB, p, F4);                                              // :48
+#pragma unroll
+    for (int k = 0; k < NS; ++k)                                          // :50-51
+      y[k] = __builtin_fma(h6, __builtin_fma(2.0, F3[k], __builtin_fma(2.0, F2[k], F1[k])) + F4[k], y[k]);
+    yc = __builtin_fma(h6, __builtin_fma(2.0, F3[NS], __builtin_fma(2.0, F2[NS], F1[NS])) + F4[NS], yc);
+    if (OUT_X && act) {
+      double* xi = xo + (size_t)(i + 1) * (NS + 1) * B;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) xi[(size_t)k * B] = y[k];
+      xi[(size_t)NS * B] = yc;
+    }
+  };
+
+  // controls are prefetched one chunk (CH steps = 2*CH samples) ahead, ping-pong in registers
+  double ub0[2 * CH][NC], ub1[2 * CH][NC];
+  auto load_chunk = [&](double (&dst)[2 * CH][NC], int c) OCS_INLINE {
+    const double* q = up + (size_t)(2 * c * CH + 1) * NC * B;
+#pragma unroll
+    for (int s = 0; s < 2 * CH; ++s)
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) dst[s][cc] = q[(size_t)(s * NC + cc) * B];
+  };
+  auto run_chunk = [&](const double (&src)[2 * CH][NC], int c) OCS_INLINE {
+#pragma unroll
+    for (int s = 0; s < CH; ++s) {
+      const double* uA = (s == 0) ? uprev : src[2 * s - 1];
+      step(c * CH + s, uA, src[2 * s], src[2 * s + 1]);
+    }
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) uprev[cc] = src[2 * CH - 1][cc];
+  };
+
+  const int nch = N / CH;
+  if (nch > 0) load_chunk(ub0, 0);
+  int c = 0;
+  for (; c + 1 < nch; c += 2) {
+    load_chunk(ub1, c + 1);
+    run_chunk(ub0, c);
+    if (c + 2 < nch) load_chunk(ub0, c + 2);
+    run_chunk(ub1, c + 1);
+  }
+  if (c < nch) run_chunk(ub0, c);
+  for (int i = nch * CH; i < N; ++i) {  // remainder steps, direct loads
+    double uM[NC], uB[NC];
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) {
+      uM[cc] = up[(size_t)((2 * i + 1) * NC + cc) * B];
+      uB[cc] = up[(size_t)((2 * i + 2) * NC + cc) * B];
+    }
+    step(i, uprev, uM, uB);
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) uprev[cc] = uB[cc];
+  }
+  if (act) a.J[b] = yc;  // J = x(end,end)   :55
+}
+
+// ---------------------------------------------------------------------------------------
+// adjoint pass: [lam, dJdu] = compute_adjoints(obj, prob, u, lamT)   RK4Integrator.m:59-121
+// ---------------------------------------------------------------------------------------
+struct BwdArgs {
+  int N, batch;
+  const double* __restrict__ HT;
+  const double* __restrict__ TC;
+  const double* __restrict__ ps;
+  const double* __restrict__ pb;
+  unsigned pmask;
+  const double* __restrict__ xck;   // checkpoints y_i = x(:,i): [N+1][nAug][B]
+  const double* __restrict__ u;
+  const double* __restrict__ lamT;  // [nAug][B] or nullptr (default e_last :63-66)
+  double* __restrict__ lam;
+  double* __restrict__ dJdu;
+};
+
+template <class P, int CH, bool OUT_LAM, bool OUT_DJDU>
+__global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
+  constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC, NAUG = P::NAUG;
+  const int b0 = blockIdx.x * 64 + threadIdx.x;
+  const bool act = b0 < a.batch;
+  const int b = act ? b0 : a.batch - 1;
+  const size_t B = (size_t)a.batch;
+  const int N = a.N;
+
+  const uniform_ptr HT = as_uniform(a.HT), TC = as_uniform(a.TC), PS = as_uniform(a.ps);
+  const typename P::Par p = P::load([&](int k) OCS_INLINE {
+    return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+  });
+
+  double lam[NS], lamc;  // lam(:,end) = lamT   :69.  lamc = lam(end,:) is constant: the last row
+  if (a.lamT) {          // of dFdx_times_vec is 0 (OCProblem.m:14-15), adding zeros is exact.
+#pragma unroll
+    for (int k = 0; k < NS; ++k) lam[k] = a.lamT[(size_t)k * B + b];
+    lamc = a.lamT[(size_t)NS * B + b];
+  } else {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) lam[k] = 0.0;
+    lamc = 1.0;
+  }
+  double* lo = a.lam + b;
+  if (OUT_LAM && act) {
+    double* q = lo + (size_t)N * NAUG * B;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) q[(size_t)k * B] = lam[k];
+    q[(size_t)NS * B] = lamc;
+  }
+  const double* up = a.u + b;
+  const double* xp = a.xck + b;
+  double* dp = a.dJdu + b;
+
+  double unext[NC], pend[NC];  // u(:,2i+3) carried from the step above; k1-term of that step
+#pragma unroll
+  for (int c = 0; c < NC; ++c) {
+    unext[c] = up[(size_t)(2 * N * NC + c) * B];
+    pend[c] = 0.0;
+  }
+
+  // reverse of RK4 step i: xi = y_i (checkpoint), controls uA (2i), uM (2i+1), uB (2i+2)
+  auto step = [&](int i, const double* xi, const double* uA, const double* uM, const double* uB) OCS_INLINE {
+    const double h = HT[4 * i], hh = HT[4 * i + 1], h6 = HT[4 * i + 2], h3 = HT[4 * i + 3];
+    double tcA[NTC], tcM[NTC], tcB[NTC];
+#pragma unroll
+    for (int k = 0; k < NTC; ++k) {
+      tcA[k] = TC[(size_t)(2 * i) * NTC + k];
+      tcM[k] = TC[(size_t)(2 * i + 1) * NTC + k];
+      tcB[k] = TC[(size_t)(2 * i + 2) * NTC + k];
+    }
+    // stage states xK(:,i,2:4), recomputed (compute_states :39-46)
+    double f[NS], Y2[NS], Y3[NS], Y4[NS];
+    P::Fx(tcA, xi, uA, p, f);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Y2[k] = __builtin_fma(hh, f[k], xi[k]);
+    P::Fx(tcM, Y2, uM, p, f);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Y3[k] = __builtin_fma(hh, f[k], xi[k]);
+    P::Fx(tcM, Y3, uM, p, f);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) Y4[k] = __builtin_fma(h, f[k], xi[k]);
+    // dJdk(:,i,4..1) and the dJdx terms   :73-88
+    double k4[NAUG], k3[NAUG], k2[NAUG], k1[NAUG], g3[NS], g2[NS], g1[NS], g0[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) k4[k] = h6 * lam[k];                          // :73
+    k4[NS] = h6 * lamc;
+    P::dFdxT(tcB, Y4, uB, p, k4, g3);                                          // :74-75
+#pragma unroll
+    for (int k = 0; k < NS; ++k) k3[k] = __builtin_fma(h, g3[k], h3 * lam[k]); // :77
+    k3[NS] = h3 * lamc;
+    P::dFdxT(tcM, Y3, uM, p, k3, g2);                                          // :78-79
+#pragma unroll
+    for (int k = 0; k < NS; ++k) k2[k] = __builtin_fma(hh, g2[k], h3 * lam[k]); // :81
+    k2[NS] = h3 * lamc;
+    P::dFdxT(tcM, Y2, uM, p, k2, g1);                                          // :82-83
+#pragma unroll
+    for (int k = 0; k < NS; ++k) k1[k] = __builtin_fma(hh, g1[k], h6 * lam[k]); // :85
+    k1[NS] = h6 * lamc;
+    P::dFdxT(tcA, xi, uA, p, k1, g0);                                          // :87-88
+    if (OUT_DJDU) {  // compute_dJdu :97-121, fused: column 2i+2 pairs k4 of step i with k1 of step i+1
+      double d4[NC], d3[NC], d2[NC];
+      P::dFduT(tcB, Y4, uB, p, k4, d4);
+      P::dFduT(tcM, Y3, uM, p, k3, d3);
+      P::dFduT(tcM, Y2, uM, p, k2, d2);
+      if (act) {
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          dp[(size_t)((2 * i + 2) * NC + c) * B] = pend[c] + d4[c];  // :112-116 (:119-120 at i = N-1)
+          dp[(size_t)((2 * i + 1) * NC + c) * B] = d2[c] + d3[c];    // :105-109
+        }
+      }
+      P::dFduT(tcA, xi, uA, p, k1, pend);
+    }
+#pragma unroll
+    for (int k = 0; k < NS; ++k) lam[k] = (((lam[k] + g1[k]) + g2[k]) + g3[k]) + g0[k];  // :86-88
+    if (OUT_LAM && act) {
+      double* q = lo + (size_t)i * NAUG * B;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) q[(size_t)k * B] = lam[k];
+      q[(size_t)NS * B] = lamc;
+    }
+  };
+
+  const int nch = N / CH;
+  // remainder steps at the top of the grid first (i = N-1 .. nch*CH), direct loads
+  for (int i = N - 1; i >= nch * CH; --i) {
+    double xi[NS], uA[NC], uM[NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) xi[k] = xp[(size_t)(i * NAUG + k) * B];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uA[c] = up[(size_t)((2 * i) * NC + c) * B];
+      uM[c] = up[(size_t)((2 * i + 1) * NC + c) * B];
+    }
+    step(i, xi, uA, uM, unext);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) unext[c] = uA[c];
+  }
+
+  // chunk c covers steps c*CH .. c*CH+CH-1: checkpoints x(:,i) and samples 2*c*CH .. 2*c*CH+2CH-1
+  double xb0[CH][NS], xb1[CH][NS], ub0[2 * CH][NC], ub1[2 * CH][NC];
+  auto load_chunk = [&](double (&xd)[CH][NS], double (&ud)[2 * CH][NC], int c) OCS_INLINE {
+    const double* qx = xp + (size_t)(c * CH) * NAUG * B;
+    const double* qu = up + (size_t)(2 * c * CH) * NC * B;
+#pragma unroll
+    for (int s = CH - 1; s >= 0; --s)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) xd[s][k] = qx[(size_t)(s * NAUG + k) * B];
+#pragma unroll
+    for (int s = 2 * CH - 1; s >= 0; --s)
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) ud[s][cc] = qu[(size_t)(s * NC + cc) * B];
+  };
+  auto run_chunk = [&](const double (&xs)[CH][NS], const double (&us)[2 * CH][NC], int c) OCS_INLINE {
+#pragma unroll
+    for (int s = CH - 1; s >= 0; --s) {
+      const double* uB = (s == CH - 1) ? unext : us[2 * s + 2];
+      step(c * CH + s, xs[s], us[2 * s], us[2 * s + 1], uB);
+    }
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) unext[cc] = us[0][cc];
+  };
+  int c = nch - 1;
+  if (c >= 0) load_chunk(xb0, ub0, c);
+  for (; c >= 1; c -= 2) {
+    load_chunk(xb1, ub1, c - 1);
+    run_chunk(xb0, ub0, c);
+    if (c >= 2) load_chunk(xb0, ub0, c - 2);
+    run_chunk(xb1, ub1, c - 1);
+  }
+  if (c == 0) run_chunk(xb0, ub0, 0);
+
+  if (OUT_DJDU && act) {
+#pragma unroll
+    for (int cc = 0; cc < NC; ++cc) dp[(size_t)cc * B] = pend[cc];  // left end point :101-102
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// plugin methods for k columns (used by the API's ocs_problem_F & friends)
+// ---------------------------------------------------------------------------------------
+template <class P>
+__global__ void k_eval(int which, int kcols, const double* __restrict__ t, const double* __restrict__ y,
+                       const double* __restrict__ u, const double* __restrict__ v,
+                       const double* __restrict__ ps, double* __restrict__ out) {
+  constexpr int NS = P::NS, NC = P::NC, NAUG = P::NAUG;
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= kcols) return;
+  const typename P::Par p = P::load([&](int k) OCS_INLINE { return ps[k]; });
+  double tc[P::NTC], tu[P::NTU], yy[NS], uu[NC], vv[NAUG];
+  P::tcoef(t[j], ps, tc, tu);
+#pragma unroll
+  for (int k = 0; k < NS; ++k) yy[k] = y[(size_t)j * NAUG + k];
+#pragma unroll
+  for (int k = 0; k < NC; ++k) uu[k] = u[(size_t)j * NC + k];
+  if (which != 0) {
+#pragma unroll
+    for (int k = 0; k < NAUG; ++k) vv[k] = v[(size_t)j * NAUG + k];
+  }
+  if (which == 0) {
+    double f[NAUG];
+    P::F(tc, yy, uu, p, f);
+#pragma unroll
+    for (int k = 0; k < NAUG; ++k) out[(size_t)j * NAUG + k] = f[k];
+  } else if (which == 1) {
+    double g[NS];
+    P::dFdxT(tc, yy, uu, p, vv, g);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) out[(size_t)j * NAUG + k] = g[k];
+    out[(size_t)j * NAUG + NS] = 0.0;
+  } else {
+    double g[NC];
+    P::dFduT(tc, yy, uu, p, vv, g);
+#pragma unroll
+    for (int k = 0; k < NC; ++k) out[(size_t)j * NC + k] = g[k];
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// layout helpers: 64x64 LDS-tiled transposes between [batch][per] and [per][batch]
+// ---------------------------------------------------------------------------------------
+// src is R x Cc row-major (R rows of Cc), dst is Cc x R row-major.
+__global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ src, double* __restrict__ dst,
+                                                   int R, int Cc) {
+  __shared__ double tile[64][65];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;  // 64 x 4
+  const int c0 = blockIdx.x * 64, r0 = blockIdx.y * 64;
+  for (int rr = ty; rr < 64; rr += 4) {
+    const int r = r0 + rr, c = c0 + tx;
+    if (r < R && c < Cc) tile[rr][tx] = src[(size_t)r * Cc + c];
+  }
+  __syncthreads();
+  for (int cc = ty; cc < 64; cc += 4) {
+    const int c = c0 + cc, r = r0 + tx;
+    if (r < R && c < Cc) dst[(size_t)c * R + r] = tile[tx][cc];
+  }
+}
+
+__global__ void k_count_nonfinite(const double* __restrict__ v, int n, int* __restrict__ count) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const bool bad = (i < n) && !isfinite(v[i]);
+  const unsigned long long m = __ballot(bad);
+  if ((threadIdx.x & 63) == 0 && m) atomicAdd(count, __popcll(m));
+}
+
+// ---------------------------------------------------------------------------------------
+// dispatch
+// ---------------------------------------------------------------------------------------
+#define OCS_DISPATCH_LOGISTIC(NSV, CALL) \
+  switch (NSV) {                         \
+    case 1: { using P = LogisticK<1>; CALL; } break; \
+    case 2: { using P = LogisticK<2>; CALL; } break; \
+    case 3: { using P = LogisticK<3>; CALL; } break; \
+    case 4: { using P = LogisticK<4>; CALL; } break; \
+    default: return -1;                  \
+  }
+
+bool functor_supported(Functor f, int nS, int nC) {
+  if (f == Functor::Logistic) return nS >= 1 && nS <= 4 && nC == 1;
+  return false;
+}
+int functor_ntc(Functor f, int nS) {
+  (void)nS;
+  if (f == Functor::Logistic) return LogisticK<1>::NTC;
+  return 0;
+}
+int functor_ntu(Functor f, int nS) {
+  (void)nS;
+  if (f == Functor::Logistic) return LogisticK<1>::NTU;
+  return 0;
+}
+unsigned functor_tc_param_mask(Functor f, int nS) {
+  (void)nS;
+  if (f == Functor::Logistic) return LogisticK<1>::TC_PARAM_MASK;
+  return 0;
+}
+
+template <class P>
+static void run_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
+  const int nT = 2 * g.N + 1;
+  k_tcoef<P><<<dim3((nT + 255) / 256), dim3(256), 0, s>>>(nT, g.T, p.ps, g.TC, g.TU);
+}
+int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
+  OCS_DISPATCH_LOGISTIC(p.nS, run_tcoef<P>(p, g, s));
+  return hip_rc(hipGetLastError());
+}
+
+constexpr int kChunk = 4;
+
+template <class P>
+static void run_forward(const FwdArgs& a, hipStream_t s) {
+  const dim3 grid((a.batch + 63) / 64), block(64);
+  if (a.x)
+    k_forward<P, kChunk, true><<<grid, block, 0, s>>>(a);
+  else
+    k_forward<P, kChunk, false><<<grid, block, 0, s>>>(a);
+}
+int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
+                   double* x, double* J, hipStream_t s) {
+  const FwdArgs a{g.N, batch, g.HT, g.TC, p.ps, p.pb, p.pmask, x0, u, x, J};
+  OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, s));
+  return hip_rc(hipGetLastError());
+}
+
+template <class P>
+static void run_backward(const BwdArgs& a, hipStream_t s) {
+  const dim3 grid((a.batch + 63) / 64), block(64);
+  if (a.lam && a.dJdu)
+    k_backward<P, kChunk, true, true><<<grid, block, 0, s>>>(a);
+  else if (a.lam)
+    k_backward<P, kChunk, true, false><<<grid, block, 0, s>>>(a);
+  else
+    k_backward<P, kChunk, false, true><<<grid, block, 0, s>>>(a);
+}
+int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                    const double* lamT, double* lam, double* dJdu, hipStream_t s) {
+  if (!lam && !dJdu) return -1;
+  const BwdArgs a{g.N, batch, g.HT, g.TC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu};
+  OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, s));
+  return hip_rc(hipGetLastError());
+}
+
+template <class P>
+static void run_eval(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
+                     const double* v, double* out, hipStream_t s) {
+  k_eval<P><<<dim3((k + 127) / 128), dim3(128), 0, s>>>(which, k, t, y, u, v, p.ps, out);
+}
+int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
+                const double* v, double* out, hipStream_t s) {
+  OCS_DISPATCH_LOGISTIC(p.nS, run_eval<P>(p, which, k, t, y, u, v, out, s));
+  return hip_rc(hipGetLastError());
+}
+
+// traj-major [batch][per]  ->  batch-minor [per][batch]
+int launch_to_batch_minor(const double* src, double* dst, int per, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(k_transpose, dim3((per + 63) / 64, (batch + 63) / 64), dim3(256), 0, s, src, dst, batch,
+                     per);
+  return hip_rc(hipGetLastError());
+}
+// batch-minor [per][batch]  ->  traj-major [batch][per]
+int launch_to_traj_major(const double* src, double* dst, int per, int batch, hipStream_t s) {
+  hipLaunchKernelGGL(k_transpose, dim3((batch + 63) / 64, (per + 63) / 64), dim3(256), 0, s, src, dst, per,
+                     batch);
+  return hip_rc(hipGetLastError());
+}
+
+int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s) {
+  hipLaunchKernelGGL(k_count_nonfinite, dim3((n + 255) / 256), dim3(256), 0, s, v, n, count);
+  return hip_rc(hipGetLastError());
+}
+
+}  // namespace ocs

@@ -1,0 +1,99 @@
+// ocs_problems.hpp -- device functors for the OCProblem plugin surface.
+//
+// The reference's plugin is three MATLAB methods (OCProblem/OCProblem.m:8-21):
+//   F(t,y,u)                 nAug x 1   (last row = objective integrand; y(end) is never read)
+//   dFdx_times_vec(t,y,u,v)  (dF/dy)' v (last row identically 0, OCProblem.m:14-15)
+//   dFdu_times_vec(t,y,u,v)  (dF/du)' v
+// A kernel cannot call back into MATLAB, so each registered problem is a struct of
+// __device__ functions that the RK4 kernels are instantiated on.  Everything that
+// depends on t only (exp(-r t) in tests/TestOCProblem.m:25,31,37) is hoisted into a
+// per-grid-point table TC filled once per (integrator, problem) pair by tcoef(): it is
+// wave-uniform, so the kernels read it with scalar loads and keep transcendental
+// calls off the serial RK4 recursion.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ocs {
+
+// LogisticK<NS>: x_k' = x_k (m_k - x_k) - u,  cost' = e^{-rt} (sum_k x_k^2 + c u^2).
+// NS = 1 with params [c r m] is tests/TestOCProblem.m (params [c m r] are permuted on the host).
+//   parameter block: [c, r, m_1 .. m_NS]
+template <int NS_>
+struct LogisticK {
+  static constexpr int NS = NS_;
+  static constexpr int NC = 1;
+  static constexpr int NAUG = NS_ + 1;
+  static constexpr int NPAR = 2 + NS_;
+  static constexpr int NTC = 1;                  // F-side time coefficients  [e^{-rt}]
+  static constexpr int NTU = 1;                  // ControlChar-side coefficients [e^{+rt}]
+  static constexpr unsigned TC_PARAM_MASK = 2u;  // r (index 1) feeds tcoef: must stay batch-uniform
+
+  struct Par {
+    double c;
+    double m[NS];
+  };
+
+  template <class Get>
+  __device__ static inline Par load(Get get) {
+    Par p;
+    p.c = get(0);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) p.m[k] = get(2 + k);
+    return p;
+  }
+
+  __device__ static inline void tcoef(double t, const double* ps, double* tc, double* tu) {
+    const double r = ps[1];
+    tc[0] = exp(-r * t);
+    tu[0] = exp(r * t);
+  }
+
+  // tests/TestOCProblem.m:22-26.  f has NAUG entries; y has NS entries (y(end) is never read).
+  __device__ static inline void F(const double* tc, const double* y, const double* u, const Par& p,
+                                  double* f) {
+    double s = y[0] * y[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) s = __builtin_fma(y[k], y[k], s);
+#pragma unroll
+    for (int k = 0; k < NS; ++k) f[k] = __builtin_fma(y[k], p.m[k] - y[k], -u[0]);
+    f[NS] = tc[0] * __builtin_fma(p.c, u[0] * u[0], s);
+  }
+  // states only (stage recomputation in the adjoint pass does not need the cost row)
+  __device__ static inline void Fx(const double* tc, const double* y, const double* u, const Par& p,
+                                   double* f) {
+    (void)tc;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) f[k] = __builtin_fma(y[k], p.m[k] - y[k], -u[0]);
+  }
+  // tests/TestOCProblem.m:29-33.  v has NAUG entries, g gets the NS non-trivial rows.
+  __device__ static inline void dFdxT(const double* tc, const double* y, const double* u, const Par& p,
+                                      const double* v, double* g) {
+    (void)u;
+    const double ev = 2.0 * tc[0] * v[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k)
+      g[k] = __builtin_fma(__builtin_fma(-2.0, y[k], p.m[k]), v[k], ev * y[k]);
+  }
+  // tests/TestOCProblem.m:36-38.  g gets NC entries.
+  __device__ static inline void dFduT(const double* tc, const double* y, const double* u, const Par& p,
+                                      const double* v, double* g) {
+    (void)y;
+    double s = -v[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) s -= v[k];
+    g[0] = __builtin_fma(2.0 * p.c * tc[0] * u[0], v[NS], s);
+  }
+  // Gen-1 ControlChar through the A9 adapter (make_from_symbolic.m:19-23,111):
+  //   dHdu = -sum(lam) + 2 c e^{-rt} u = 0  ->  u = sum(lam) e^{rt} / (2c), clamped to the bounds.
+  __device__ static inline void control_char(const double* tu, const double* x, const double* lam,
+                                             const Par& p, const double* lb, const double* ub, double* u) {
+    (void)x;
+    double s = lam[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) s += lam[k];
+    const double v = s * tu[0] / (2.0 * p.c);
+    u[0] = fmin(ub[0], fmax(lb[0], v));
+  }
+};
+
+}  // namespace ocs

@@ -1,0 +1,105 @@
+"""OCProblem plugin (reference: OCProblem/OCProblem.m, tests/TestOCProblem.m).
+
+A kernel cannot call back into a user method, so a problem is a registry id plus a
+parameter block (include/ocs.h); F / dFdx_times_vec / dFdu_times_vec keep their names,
+argument order and shapes and are evaluated by the device functor.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, dp, lib
+
+PROBLEM_TEST, PROBLEM_LOGISTIC = 1, 2
+
+
+def _f(a, shape=None):
+    a = np.asarray(a, dtype=np.float64)
+    if shape is not None:
+        a = a.reshape(shape, order="F")
+    return np.asfortranarray(a)
+
+
+def _p(a):
+    return None if a is None else a.ctypes.data_as(dp)
+
+
+class OCProblem:
+    """OCProblem/OCProblem.m:1-24 -- abstract interface; concrete problems come from the registry."""
+
+    def __init__(self, problem_id, nS, nC, params, ControlBounds):
+        self.nS, self.nC, self.nAug = int(nS), int(nC), int(nS) + 1
+        self.params = _f(params).ravel()
+        self.ControlBounds = _f(ControlBounds, (self.nC, 2))
+        h = C.c_void_p()
+        check(lib.ocs_problem_create(C.byref(h), problem_id, self.nS, self.nC, _p(self.params),
+                                     self.params.size, _p(self.ControlBounds)))
+        self._h = h
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h and lib is not None:
+            lib.ocs_problem_destroy(h)
+            self._h = None
+
+    def set_batch_params(self, index, values):
+        """Per-trajectory overrides (batch extension): values is len(index) x batch."""
+        index = np.asarray(index, dtype=np.int32).ravel()
+        if index.size == 0:
+            check(lib.ocs_problem_set_batch_params(self._h, 0, None, 0, None))
+            return
+        values = _f(np.atleast_2d(values))
+        if values.shape[0] != index.size:
+            raise ValueError("values must be len(index) x batch")
+        check(lib.ocs_problem_set_batch_params(self._h, values.shape[1],
+                                               index.ctypes.data_as(_lib.ip), index.size, _p(values)))
+
+    def _cols(self, t):
+        t = _f(np.atleast_1d(t)).ravel()
+        return t, t.size
+
+    def F(self, t, y, u):
+        """OCProblem.m:12 / TestOCProblem.m:22-26"""
+        t, k = self._cols(t)
+        y, u = _f(y, (self.nAug, k)), _f(u, (self.nC, k))
+        out = np.empty((self.nAug, k), order="F")
+        check(lib.ocs_problem_F(self._h, k, _p(t), _p(y), _p(u), _p(out)))
+        return out
+
+    def dFdx_times_vec(self, t, y, u, v):
+        """OCProblem.m:16 / TestOCProblem.m:29-33"""
+        t, k = self._cols(t)
+        y, u, v = _f(y, (self.nAug, k)), _f(u, (self.nC, k)), _f(v, (self.nAug, k))
+        out = np.empty((self.nAug, k), order="F")
+        check(lib.ocs_problem_dFdx_times_vec(self._h, k, _p(t), _p(y), _p(u), _p(v), _p(out)))
+        return out
+
+    def dFdu_times_vec(self, t, y, u, v):
+        """OCProblem.m:19 / TestOCProblem.m:36-38"""
+        t, k = self._cols(t)
+        y, u, v = _f(y, (self.nAug, k)), _f(u, (self.nC, k)), _f(v, (self.nAug, k))
+        out = np.empty((self.nC, k), order="F")
+        check(lib.ocs_problem_dFdu_times_vec(self._h, k, _p(t), _p(y), _p(u), _p(v), _p(out)))
+        return out
+
+
+class TestOCProblem(OCProblem):
+    """tests/TestOCProblem.m:16-20: prob = TestOCProblem(p, ControlBounds), p has fields c, m, r."""
+    __test__ = False
+
+    def __init__(self, p, ControlBounds):
+        self.c, self.m, self.r = float(p["c"]), float(p["m"]), float(p["r"])
+        super().__init__(PROBLEM_TEST, 1, 1, [self.c, self.m, self.r], ControlBounds)
+
+
+class LogisticProblem(OCProblem):
+    """LogisticK (build-defined generalisation): nS uncoupled logistic states
+    sharing one harvest control; nS = 1 is TestOCProblem."""
+
+    def __init__(self, m, c, r, ControlBounds):
+        m = np.atleast_1d(np.asarray(m, dtype=np.float64))
+        self.c, self.m, self.r = float(c), m, float(r)
+        super().__init__(PROBLEM_LOGISTIC, m.size, 1, np.concatenate([[c, r], m]), ControlBounds)

@@ -1,0 +1,162 @@
+/*
+ * ocs_oracle.h -- CPU restatement (plain C, fp64) of the reference's RK4 state /
+ * discrete-adjoint / forward-backward-sweep hot path.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing in the product path (the package
+ * optimal-control-solvers_amd/, libocs.so) may include, link or call this.
+ * Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg use it,
+ * and there only as the checker / the timed CPU baseline.
+ *
+ * PARITY UNPINNED: the reference (DrDanRyan/Optimal-Control-Solvers) is pure
+ * MATLAB with no golden vectors, no asserts and no fixtures in its tests
+ * (tests/backprop_test.m prints two numbers for an unseeded rand), and neither
+ * MATLAB nor Octave exists in this pipeline, so this restatement has never been
+ * compared with output of the reference itself.  It is anchored instead on
+ * analytic known answers, complex-step / finite-difference gradient checks and
+ * an independent NumPy twin (oracle/np_twin.py); see tests/test_oracle_*.py.
+ *
+ * Every function cites the reference file:line it follows (paths relative to
+ * the reference root).  All matrices are column-major, exactly the MATLAB
+ * shapes: x is nAug x (N+1), u is nC x (2N+1), lam is nAug x (N+1).
+ */
+#ifndef OCS_ORACLE_H
+#define OCS_ORACLE_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- problem registry (same ids / parameter blocks as include/ocs.h) ---- */
+#define OCS_OR_PROBLEM_TEST 1     /* tests/TestOCProblem.m      params [c m r]            */
+#define OCS_OR_PROBLEM_LOGISTIC 2 /* build-defined LogisticK    params [c r m_1..m_nS]    */
+#define OCS_OR_PROBLEM_LQ 3       /* build-defined LQ           params [r A Bu q rdiag]   */
+
+typedef struct ocs_or_problem ocs_or_problem;
+
+/* bounds: nC x 2 column-major [lb ; ub] like prob.ControlBounds (OCProblem.m:3-5) */
+ocs_or_problem *ocs_or_problem_create(int id, int nS, int nC, const double *params, int nparams,
+                                      const double *bounds);
+void ocs_or_problem_destroy(ocs_or_problem *p);
+int ocs_or_problem_nS(const ocs_or_problem *p);
+int ocs_or_problem_nC(const ocs_or_problem *p);
+
+/* OCProblem plugin methods, vectorised over k columns (OCProblem.m:8-21) */
+void ocs_or_F(const ocs_or_problem *p, int k, const double *t, const double *y, const double *u,
+              double *out /* nAug x k */);
+void ocs_or_dFdx_times_vec(const ocs_or_problem *p, int k, const double *t, const double *y,
+                           const double *u, const double *v, double *out /* nAug x k */);
+void ocs_or_dFdu_times_vec(const ocs_or_problem *p, int k, const double *t, const double *y,
+                           const double *u, const double *v, double *out /* nC x k */);
+/* Gen-2 -> Gen-1 adapter (make_from_symbolic.m:11-17,102-112; compute_equilibrium.m:14-20) */
+void ocs_or_stateRHS(const ocs_or_problem *p, int k, const double *t, const double *x, const double *u,
+                     double *out /* nS x k */);
+void ocs_or_objective(const ocs_or_problem *p, int k, const double *t, const double *x, const double *u,
+                      double *out /* 1 x k */);
+void ocs_or_adjointRHS(const ocs_or_problem *p, int k, const double *t, const double *x,
+                       const double *lam, const double *u, double *out /* nS x k */);
+void ocs_or_ControlChar(const ocs_or_problem *p, int k, const double *t, const double *x,
+                        const double *lam, double *out /* nC x k */);
+
+/* ---- helpers ---- */
+void ocs_or_linspace(double a, double b, int n, double *out); /* MATLAB linspace */
+/* griddedInterpolant(x, v, method) evaluated at xq; method: 0 linear, 1 nearest-extrap linear
+ * (the 'linear','nearest' pair of PWLinearControl.m:35), 2 previous, 3 pchip. */
+void ocs_or_interp1(int n, const double *x, const double *v, int method, int nq, const double *xq,
+                    double *out);
+void ocs_or_pchip_slopes(int n, const double *x, const double *y, double *d);
+/* vectorInterpolant(x, v, method)(tq) for an nComp x n sample matrix (functions/vectorInterpolant.m:1-12) */
+void ocs_or_vector_interp(int nComp, int n, const double *x, const double *v, int method, int nq,
+                          const double *tq, double *out /* nComp x nq */);
+
+/* ---- Integrator/RK4Integrator.m ---- */
+typedef struct ocs_or_rk4 ocs_or_rk4;
+ocs_or_rk4 *ocs_or_rk4_create(const double *tspan, int npts);           /* :16-25 */
+void ocs_or_rk4_destroy(ocs_or_rk4 *g);
+int ocs_or_rk4_nsteps(const ocs_or_rk4 *g);
+const double *ocs_or_rk4_t(const ocs_or_rk4 *g);                        /* property t, 2N+1 */
+const double *ocs_or_rk4_h(const ocs_or_rk4 *g);                        /* property h, N    */
+const double *ocs_or_rk4_xK(const ocs_or_rk4 *g);                       /* nAug x (N+1) x 4 */
+/* [x, J] = compute_states(obj, prob, x0, u)   :28-56 */
+void ocs_or_rk4_compute_states(ocs_or_rk4 *g, const ocs_or_problem *p, const double *x0,
+                               const double *u, double *x, double *J);
+/* [lam, dJdu] = compute_adjoints(obj, prob, u, lamT)   :59-94 (+ compute_dJdu :97-121)
+ * lamT may be NULL (default e_last), dJdu may be NULL (nargout == 1). */
+void ocs_or_rk4_compute_adjoints(ocs_or_rk4 *g, const ocs_or_problem *p, const double *u,
+                                 const double *lamT, double *lam, double *dJdu);
+
+/* ---- Integrator/RK4InfiniteIntegrator.m ---- */
+typedef struct ocs_or_rk4inf ocs_or_rk4inf;
+ocs_or_rk4inf *ocs_or_rk4inf_create(const double *tspan, int npts, const double *tspanExtra,
+                                    int nptsExtra, const double *uStar, int nC); /* :12-17 */
+void ocs_or_rk4inf_destroy(ocs_or_rk4inf *g);
+const double *ocs_or_rk4inf_t(const ocs_or_rk4inf *g);
+int ocs_or_rk4inf_nsteps(const ocs_or_rk4inf *g);
+void ocs_or_rk4inf_compute_states(ocs_or_rk4inf *g, const ocs_or_problem *p, const double *x0,
+                                  const double *u, double *x, double *J);        /* :20-24 */
+void ocs_or_rk4inf_compute_adjoints(ocs_or_rk4inf *g, const ocs_or_problem *p, const double *u,
+                                    double *lam, double *dJdu);                   /* :27-30 */
+
+/* ---- Control classes (Control/PWLinearControl.m, PWConstantControl.m, ChebyshevControl.m) ---- */
+#define OCS_OR_CONTROL_PWLINEAR 1
+#define OCS_OR_CONTROL_PWCONSTANT 2
+#define OCS_OR_CONTROL_CHEBYSHEV 3
+typedef struct ocs_or_control ocs_or_control;
+ocs_or_control *ocs_or_control_create(int kind, const double *t, int nt, int nBasis, int nControls);
+void ocs_or_control_destroy(ocs_or_control *c);
+int ocs_or_control_nbasis(const ocs_or_control *c);
+const double *ocs_or_control_B(const ocs_or_control *c);   /* nBasis x nt */
+const double *ocs_or_control_pts(const ocs_or_control *c); /* controlPts / intervalStarts */
+void ocs_or_control_compute_u(const ocs_or_control *c, const double *v, double *u);       /* u = reshape(v,nC,[])*B */
+void ocs_or_control_compute_dJdv(const ocs_or_control *c, const double *dJdu, double *dJdv); /* dJdu*B' */
+int ocs_or_control_compute_initial_v(const ocs_or_control *c, const double *u0, int len_u0, double *v);
+void ocs_or_control_compute_nlp_bounds(const ocs_or_control *c, const double *bounds, double *Lb,
+                                       double *Ub);
+/* uFunc = compute_uFunc(v); out = uFunc(tq)  (PWLinearControl.m:74-77, PWConstantControl.m:58-61;
+ * Chebyshev: build-defined Clenshaw-free direct recurrence, ChebyshevControl.m:21-31) */
+void ocs_or_control_eval_uFunc(const ocs_or_control *c, const double *v, int nq, const double *tq,
+                               double *out);
+
+/* ---- functions/single_shooting.m:137-150 nlpObjective ----
+ * v has nC*nBasis (+ nFree) entries; FreeInitStates are 1-based like MATLAB.
+ * integ_kind 0: RK4Integrator, 1: RK4InfiniteIntegrator (g is the matching handle). */
+void ocs_or_nlp_objective(int integ_kind, void *g, const ocs_or_problem *p, const ocs_or_control *c,
+                          double *x0 /* in/out: overwritten at FreeInitStates */, const double *v,
+                          int nFree, const int *FreeInitStates, double *J, double *dJdv);
+
+/* ---- functions/compute_x_lam.m, compute_x_lam_J.m, fb_sweep.m on the grid ----
+ * Build-defined discretisation: odevr7 is replaced by classical
+ * RK4 on the integrator's node grid with u sampled on the 2N+1 grid, x(t)/lam(t)
+ * are pchip interpolants of the node values exactly as compute_x_lam.m:9,17. */
+typedef struct {
+  double uRelTol, uAbsTol; /* fb_sweep.m:16-17 */
+  int nSWEEPS;             /* :20 */
+  int nERROR_PTS;          /* :21 */
+  int nINTERP_PTS;         /* :22 */
+} ocs_or_fbs_options;
+void ocs_or_fbs_default_options(ocs_or_fbs_options *o);
+/* ugrid: nC x (2N+1) samples of u on the grid.  x: nS x (N+1), lam: nS x (N+1), J optional */
+void ocs_or_compute_x_lam(const ocs_or_rk4 *g, const ocs_or_problem *p, const double *x0,
+                          const double *ugrid, double *x, double *lam, double *J);
+/* u(tq) = ControlChar(tq, x(tq), lam(tq)) with pchip x, lam (fb_sweep.m:96) */
+void ocs_or_control_from_x_lam(const ocs_or_rk4 *g, const ocs_or_problem *p, const double *x,
+                               const double *lam, int nq, const double *tq, double *out);
+/* Full sweep loop.  u0grid: nC x (2N+1), u0err: nC x nERROR_PTS (u0 sampled by the caller).
+ * Returns the 1-based sweep index at which convergence was detected, or 0 (soln stays empty).
+ * maxChange[nSWEEPS] receives the printed "Normalized change in u" per sweep (fb_sweep.m:109). */
+int ocs_or_fb_sweep(const ocs_or_rk4 *g, const ocs_or_problem *p, const double *x0,
+                    const ocs_or_fbs_options *o, const double *u0grid, const double *u0err,
+                    double *x, double *lam, double *uInterp /* nC x nINTERP_PTS */, double *J,
+                    double *maxChange);
+
+/* ---- batch drivers used only for the cpu_baseline timing (OpenMP over the batch) ----
+ * Arrays are trajectory-major: trajectory b occupies a contiguous MATLAB-shaped block. */
+int ocs_or_max_threads(void);
+void ocs_or_batch_states_adjoints(int id, int nS, int nC, const double *params, int nparams,
+                                  const double *bounds, const double *tspan, int npts, int batch,
+                                  const double *x0 /* nS x batch */, const double *u /* nC x (2N+1) x batch */,
+                                  double *x, double *J, double *lam, double *dJdu, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
