@@ -1,0 +1,215 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the RK4 state + discrete-adjoint hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): LogisticK with nS = 4 (nAug = 5,
+nC = 1), N = 1000 RK4 steps on linspace(0, 10, 1001), batch = 4096 control candidates per
+GPU, fp64, full-output mode (x, J, lam, dJdu all written).  One "step" of this script is one
+pass of the hot path over the batch: compute_states followed by compute_adjoints, i.e.
+batch * N fused RK4 state+costate steps.  Inputs are synthetic and already resident in HBM.
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+         --master-port P bench.py --gpus N --steps K --warmup W
+
+Multi-GPU: the batch axis shards with no data-path exchange (weak scaling, 4096 per GPU); the
+only collective is the all-reduce(SUM) of the objective sum over ranks (north_star), 8 bytes.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+NS, NC, NSTEPS, BATCH = 4, 1, 1000, 4096
+M, C_PAR, R_PAR = [3.0, 2.5, 2.0, 1.5], 1.5, 0.05
+T_END = 10.0
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def make_inputs(batch, device, seed):
+    """SURVEY BL-2 candidates u_b(t) = clamp(a + A sin(2 pi f_b t + phi_b), 0, 1), seeded; amplitude
+    (a, A) = (0.25, 0.2) instead of the survey's (0.5, 0.4), which drives the m = 1.5 state to -inf."""
+    rng = np.random.default_rng(seed)
+    tspan = np.linspace(0.0, T_END, NSTEPS + 1)
+    t = np.zeros(2 * NSTEPS + 1)
+    t[0::2] = tspan
+    t[1::2] = (tspan[:-1] + tspan[1:]) / 2
+    f, ph = rng.uniform(0, 1, batch), rng.uniform(0, 2 * np.pi, batch)
+    u = np.clip(0.25 + 0.2 * np.sin(2 * np.pi * f[None, :] * t[:, None] + ph[None, :]), 0.0, 1.0)
+    u = np.ascontiguousarray(u[:, None, :])                      # [2N+1][nC][B] batch-minor
+    x0 = np.ones((NS, batch))
+    return tspan, x0, u
+
+
+def cpu_baseline(tspan, x0, u, target_seconds=12.0):
+    """Times the CPU oracle (the C restatement of RK4Integrator.m, OpenMP over the batch) on the
+    same workload: kind 'port'.  Bounded: repeats whole-batch passes until ~target_seconds."""
+    from oracle import oracle as orc
+    orc.build()
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:  # cgroup quota of the GPU box (16 CPUs for one GPU)
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = max(1, min(cores, int(int(q) / int(p))))
+    except Exception:
+        pass
+    cores = min(cores, orc.max_threads())
+    prob = orc.LogisticProblem(M, C_PAR, R_PAR, [[0.0, 1.0]])
+    u_m = np.asfortranarray(u.transpose(1, 0, 2))               # nC x (2N+1) x B, MATLAB shape
+    out = orc.batch_states_adjoints(prob, tspan, x0, u_m, nthreads=cores)  # warm-up, touches outputs
+    t0 = time.perf_counter()
+    passes = 0
+    while True:
+        orc.batch_states_adjoints(prob, tspan, x0, u_m, nthreads=cores, out=out)
+        passes += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_seconds or passes >= 200:
+            break
+    batch = x0.shape[1]
+    return {"value": batch * NSTEPS * passes / dt, "unit": "RK4 state+costate steps/s", "cores": cores,
+            "kind": "port",
+            "sample": f"{passes} full passes of the bench workload (batch {batch} x {NSTEPS} steps, "
+                      f"x/J/lam/dJdu written) in {dt:.1f} s, oracle/ocs_oracle.c with OpenMP over the batch"}, out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=BATCH, help="trajectories per GPU (default: BASELINE config)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    torch.cuda.set_device(dev)
+
+    import __graft_entry__ as ge
+    ocs = ge.load_package()  # raises if libocs.so is missing: no fallback path
+
+    batch = args.batch
+    tspan, x0_h, u_h = make_inputs(batch, dev, 20260401 + rank)
+    prob = ocs.LogisticProblem(M, C_PAR, R_PAR, [[0.0, 1.0]])
+    integ = ocs.RK4Integrator(tspan)
+    x0 = torch.tensor(x0_h, device=dev)
+    u = torch.tensor(u_h, device=dev)
+    x = torch.empty((NSTEPS + 1, NS + 1, batch), dtype=torch.float64, device=dev)
+    lam = torch.empty_like(x)
+    dJdu = torch.empty_like(u)
+    J = torch.empty(batch, dtype=torch.float64, device=dev)
+    Jsum = torch.zeros(1, dtype=torch.float64, device=dev)
+
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
+
+    def one_step(k=None):
+        if k is not None:
+            ev[k][0].record()
+        integ.compute_states_dev(prob, x0, u, x, J)
+        if k is not None:
+            ev[k][1].record()
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+        if k is not None:
+            ev[k][2].record()
+        if world > 1:
+            torch.sum(J, dim=0, keepdim=True, out=Jsum)
+            dist.all_reduce(Jsum)
+
+    for _ in range(args.warmup):
+        one_step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        one_step(k)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+
+    # per-kernel durations from HIP events on the launch stream (torch's current stream)
+    t_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+    t_bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    nA = NS + 1
+    bytes_fwd = 8 * (nA + 2 * NC) * batch * NSTEPS           # write x, read u (2 new samples/step)
+    bytes_bwd = 8 * (2 * nA + 4 * NC) * batch * NSTEPS       # read x, write lam, read u, write dJdu
+    ok = bool(torch.isfinite(J).all().item()) and bool(torch.isfinite(dJdu).all().item())
+
+    if rank == 0:
+        steps_total = world * batch * NSTEPS * args.steps
+        traffic = None
+        tr_path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+        if os.path.exists(tr_path):
+            try:
+                tr = json.load(open(tr_path))
+                if tr.get("batch") == batch and tr.get("kernel") == "k_backward":
+                    traffic = tr.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "RK4 state+costate steps/sec (batch*nSteps)",
+            "value": steps_total / dt,
+            "unit": "steps/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": "BL-2: LogisticK nS=4 (nAug=5, nC=1), 1000 RK4 steps, "
+                                   f"batch={batch} control candidates per GPU, full output (x,J,lam,dJdu)",
+                       "problem": "LogisticK(m=[3,2.5,2,1.5], c=1.5, r=0.05)", "n_steps": NSTEPS,
+                       "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}",
+                       "mapping": "lane-per-trajectory"},
+            "roofline": {"bound": "hbm", "kernel": "k_backward (compute_adjoints + compute_dJdu)",
+                         "achieved": bytes_bwd / t_bwd / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": bytes_bwd / t_bwd / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                         "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_s": t_bwd},
+            "kernels": {"k_forward": {"avg_s": t_fwd, "alg_bytes": bytes_fwd,
+                                      "GBps": bytes_fwd / t_fwd / 1e9},
+                        "k_backward": {"avg_s": t_bwd, "alg_bytes": bytes_bwd,
+                                       "GBps": bytes_bwd / t_bwd / 1e9},
+                        "pass_pair_GBps": (bytes_fwd + bytes_bwd) / (t_fwd + t_bwd) / 1e9,
+                        "pass_pair_frac": (bytes_fwd + bytes_bwd) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBPS},
+            "finite": ok,
+        }
+        if not args.no_cpu_baseline and world == 1:
+            cb, ref = cpu_baseline(tspan, x0_h, u_h)
+            line["cpu_baseline"] = cb
+            # the baseline run doubles as a parity check of the timed buffers
+            err = float(np.max(np.abs(J.cpu().numpy() - ref["J"]) / np.maximum(1.0, np.abs(ref["J"]))))
+            line["parity_J_max_rel_err_vs_oracle"] = err
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

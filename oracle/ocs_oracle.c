@@ -406,6 +406,8 @@ struct ocs_or_rk4 {
   double *h;  /* 1 x N */
   int nAug;   /* rows of xK (set by compute_states) */
   double *xK; /* nAug x (N+1) x 4 */
+  double *dJdk; /* nAug x N x 4 scratch of compute_adjoints, kept between calls */
+  size_t xK_cap, dJdk_cap;
 };
 
 /* RK4Integrator.m:16-25 */
@@ -426,6 +428,7 @@ void ocs_or_rk4_destroy(ocs_or_rk4 *g) {
   free(g->t);
   free(g->h);
   free(g->xK);
+  free(g->dJdk);
   free(g);
 }
 int ocs_or_rk4_nsteps(const ocs_or_rk4 *g) { return g->nSTEPS; }
@@ -440,10 +443,13 @@ void ocs_or_rk4_compute_states(ocs_or_rk4 *g, const ocs_or_problem *p, const dou
                                const double *u, double *x, double *J) {
   const int nSTATES = p->nS + 1; /* :29 */
   const int N = g->nSTEPS, nC = p->nC;
-  free(g->xK);
   g->nAug = nSTATES;
   const size_t tot = (size_t)nSTATES * (N + 1) * 4;
-  g->xK = (double *)malloc(sizeof(double) * tot);
+  if (tot > g->xK_cap) { /* storage is reused between calls; the NaN fill below is the reference's :32 */
+    free(g->xK);
+    g->xK = (double *)malloc(sizeof(double) * tot);
+    g->xK_cap = tot;
+  }
   for (size_t i = 0; i < tot; ++i) g->xK[i] = NAN; /* :32 */
   for (int r = 0; r < p->nS; ++r) XK(g, r, 0, 0) = x0[r];
   XK(g, nSTATES - 1, 0, 0) = 0.0; /* :33 */
@@ -481,7 +487,12 @@ void ocs_or_rk4_compute_adjoints(ocs_or_rk4 *g, const ocs_or_problem *p, const d
 #define DJDK(r, c, s) dJdk[(r) + LD * ((c) + (size_t)N * (s))]
   for (int r = 0; r < nSTATES; ++r)
     LAM(r, N) = lamT ? lamT[r] : (r == nSTATES - 1 ? 1.0 : 0.0); /* :63-69 */
-  double *dJdk = (double *)malloc(sizeof(double) * LD * N * 4);  /* :70 */
+  if (LD * N * 4 > g->dJdk_cap) {
+    free(g->dJdk);
+    g->dJdk = (double *)malloc(sizeof(double) * LD * N * 4);
+    g->dJdk_cap = LD * N * 4;
+  }
+  double *dJdk = g->dJdk; /* :70 */
   double *dJdx1 = (double *)malloc(sizeof(double) * 4 * LD);
   double *dJdx2 = dJdx1 + LD, *dJdx3 = dJdx2 + LD, *dJdx0 = dJdx3 + LD;
 
@@ -539,7 +550,6 @@ void ocs_or_rk4_compute_adjoints(ocs_or_rk4 *g, const ocs_or_problem *p, const d
     free(tt);
     free(uu);
   }
-  free(dJdk);
   free(dJdx1);
 #undef LAM
 #undef DJDK

@@ -467,18 +467,20 @@ def max_threads():
     return lib().ocs_or_max_threads()
 
 
-def batch_states_adjoints(prob, tspan, x0, u, nthreads=1, want=("x", "J", "lam", "dJdu")):
-    """OpenMP-over-batch driver for the cpu_baseline timing.  x0: nS x batch, u: nC x (2N+1) x batch."""
+def batch_states_adjoints(prob, tspan, x0, u, nthreads=1, want=("x", "J", "lam", "dJdu"), out=None):
+    """OpenMP-over-batch driver for the cpu_baseline timing.  x0: nS x batch, u: nC x (2N+1) x batch.
+    Pass the dict returned by an earlier call as `out` to reuse (already touched) output arrays."""
     tspan = _f(tspan).ravel()
     N = tspan.size - 1
     x0 = _f(np.atleast_2d(x0))
     batch = x0.shape[1]
     u = _f(u, (prob.nC, 2 * N + 1, batch))
-    out = {}
-    out["x"] = np.empty((prob.nAug, N + 1, batch), order="F") if "x" in want else None
-    out["J"] = np.empty(batch) if "J" in want else None
-    out["lam"] = np.empty((prob.nAug, N + 1, batch), order="F") if "lam" in want else None
-    out["dJdu"] = np.empty((prob.nC, 2 * N + 1, batch), order="F") if "dJdu" in want else None
+    if out is None:
+        out = {}
+        out["x"] = np.empty((prob.nAug, N + 1, batch), order="F") if "x" in want else None
+        out["J"] = np.empty(batch) if "J" in want else None
+        out["lam"] = np.empty((prob.nAug, N + 1, batch), order="F") if "lam" in want else None
+        out["dJdu"] = np.empty((prob.nC, 2 * N + 1, batch), order="F") if "dJdu" in want else None
     lib().ocs_or_batch_states_adjoints(prob.id, prob.nS, prob.nC, _p(prob.params), prob.params.size,
                                        _p(prob.ControlBounds), _p(tspan), tspan.size, batch, _p(x0),
                                        _p(u), _p(out["x"]), _p(out["J"]), _p(out["lam"]),
