@@ -12,7 +12,7 @@ import re
 import torch  # noqa: F401  (first: makes torch's libamdhip64.so.7 the process-wide HIP runtime)
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libocs.so")
+LIB_PATH = os.environ.get("OCS_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "libocs.so")  # override: tuning builds only
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "ocs.h")
 
 dp = C.POINTER(C.c_double)

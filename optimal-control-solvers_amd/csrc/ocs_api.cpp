@@ -104,7 +104,7 @@ struct ocs_problem_s {
 struct ocs_integrator_s {
   int N = 0;
   std::vector<double> tspan, t, h;
-  DevBuf d_HT, d_T, d_TC, d_TU;
+  DevBuf d_HT, d_T, d_TC, d_TU, d_REC;
   bool grid_uploaded = false;
   unsigned long long tc_version = 0;  // version of the problem TC was built for
   const ocs_problem_s* tc_prob = nullptr;
@@ -171,6 +171,7 @@ static GridDesc describe(const ocs_integrator_s* g) {
   d.T = g->d_T.d();
   d.TC = g->d_TC.d();
   d.TU = g->d_TU.d();
+  d.REC = g->d_REC.d();
   return d;
 }
 
@@ -186,6 +187,7 @@ static int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStr
     const int ntu = functor_ntu(p->functor, p->nS);
     OCS_TRY(g->d_TC.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * ntc));
     OCS_TRY(g->d_TU.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * (ntu > 0 ? ntu : 1)));
+    OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)g->N * rec_stride_host(ntc)));
     LAUNCH_TRY(launch_tcoef(describe(p), describe(g), s));
     g->tc_prob = p;
     g->tc_version = p->version;
@@ -383,7 +385,7 @@ int ocs_rk4_create(ocs_integrator* out, const double* tspan, int npts) {
 int ocs_integrator_destroy(ocs_integrator g) {
   if (!g) return OCS_OK;
   if (g->stream) (void)hipStreamDestroy(g->stream);
-  DevBuf* bufs[] = {&g->d_HT, &g->d_T, &g->d_TC, &g->d_TU, &g->d_x0, &g->d_u, &g->d_x, &g->d_J,
+  DevBuf* bufs[] = {&g->d_HT, &g->d_T, &g->d_TC, &g->d_TU, &g->d_REC, &g->d_x0, &g->d_u, &g->d_x, &g->d_J,
                     &g->d_lam, &g->d_dJdu, &g->d_lamT, &g->d_stage, &g->d_ck};
   for (DevBuf* b : bufs) b->release();
   delete g;

@@ -26,6 +26,7 @@ struct GridDesc {
   const double* T;    // device: [2N+1] grid times (obj.t)
   double* TC;         // device: [2N+1][NTC] time coefficients of the bound problem (F side)
   double* TU;         // device: [2N+1][NTU] time coefficients of its ControlChar
+  double* REC;        // device: [N][rec_stride(NTC)] per-step records {h,h/2,h/6,h/3,tcA,tcM,tcB}
 };
 
 // Device-native layouts (batch-minor): x0 [nS][B], u [2N+1][nC][B], x [N+1][nAug][B],
@@ -48,6 +49,7 @@ int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s);
 bool functor_supported(Functor f, int nS, int nC);
 int functor_ntc(Functor f, int nS);
 int functor_ntu(Functor f, int nS);
+int rec_stride_host(int ntc);
 unsigned functor_tc_param_mask(Functor f, int nS);
 
 }  // namespace ocs

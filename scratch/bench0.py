@@ -26,6 +26,8 @@ def run(nS, N, batch, reps=10):
     bytes_ = 8 * (3 * nA + 6) * batch * N
     print(f"nS={nS} N={N} batch={batch}: fwd {tf*1e3:.1f} us  bwd {tb*1e3:.1f} us  steps/s {batch*N/((tf+tb)*1e-3):.3e}  "
           f"alg GB/s {bytes_/((tf+tb)*1e-3)/1e9:.1f}  frac {bytes_/((tf+tb)*1e-3)/8e12:.3f}", flush=True)
+import os
+batches = [int(b) for b in os.environ.get("BATCHES", "4096,16384,65536,262144").split(",")]
 for nS in (4, 1):
-    for batch in (4096, 16384, 65536, 262144):
+    for batch in batches:
         run(nS, 1000, batch)
