@@ -114,6 +114,49 @@ int ocs_compute_states_dev(ocs_integrator g, ocs_problem p, int batch, const dou
 int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const double *u,
                              const double *lamT, double *lam, double *dJdu, void *stream);
 
+/* obj = RK4InfiniteIntegrator(tspan, tspanExtra, uStar)   Integrator/RK4InfiniteIntegrator.m:12-17
+ * compute_states/adjoints on this handle follow :20-30 (J = J1 + J2; terminal adjoint of leg 1 =
+ * lam2(:,1) of the tail leg under the constant control uStar); lamT must be NULL. */
+int ocs_rk4inf_create(ocs_integrator *out, const double *tspan, int npts, const double *tspanExtra,
+                      int nptsExtra, const double *uStar, int nC);
+
+/* ---- Control (Control/Control.m:4-14 and PWLinearControl.m / PWConstantControl.m / ChebyshevControl.m) ----
+ * v is a column with the control index fastest: v(c + nC*(i-1)), i = basis function. */
+int ocs_control_create(ocs_control *out, int kind, const double *t, int nt, int nBasis, int nControls);
+int ocs_control_destroy(ocs_control c);
+int ocs_control_dims(ocs_control c, int *nBasis, int *nControls, int *nt);
+int ocs_control_basis(ocs_control c, double *B);    /* property B, nBasis x nt          */
+int ocs_control_points(ocs_control c, double *pts); /* controlPts / intervalStarts      */
+/* u = compute_u(obj, v)            host: v (nC*nBasis) x batch -> u nC x nt x batch      */
+int ocs_control_compute_u(ocs_control c, int batch, const double *v, double *u);
+/* dJdv = compute_dJdv(obj, dJdu)   host: dJdu nC x nt x batch -> dJdv (nC*nBasis) x batch */
+int ocs_control_compute_dJdv(ocs_control c, int batch, const double *dJdu, double *dJdv);
+/* device, batch-minor: v / dJdv [nBasis][nC][batch], u / dJdu [nt][nC][batch] */
+int ocs_control_compute_u_dev(ocs_control c, int batch, const double *v, double *u, void *stream);
+int ocs_control_compute_dJdv_dev(ocs_control c, int batch, const double *dJdu, double *dJdv, void *stream);
+/* v = compute_initial_v(obj, u0)   PWLinearControl.m:65-71, PWConstantControl.m:53-55, ChebyshevControl.m:46-48 */
+int ocs_control_compute_initial_v(ocs_control c, const double *u0, int len_u0, double *v);
+/* [Lb, Ub] = compute_nlp_bounds(obj, controlBounds)   PWLinearControl.m:21-28 */
+int ocs_control_compute_nlp_bounds(ocs_control c, const double *bounds, double *Lb, double *Ub);
+/* uFunc = compute_uFunc(obj, v); out = uFunc(tq)      PWLinearControl.m:74-77, PWConstantControl.m:58-61 */
+int ocs_control_eval_uFunc(ocs_control c, const double *v, int nq, const double *tq, double *out);
+
+/* vectorInterpolant(x, v, method)(tq)   functions/vectorInterpolant.m:1-12; v nComp x n, out nComp x nq.
+ * This is the "griddedInterpolant-compatible" output: solvers return sample arrays, the caller wraps them. */
+int ocs_interp(int method, int nComp, int n, const double *x, const double *v, int nq, const double *tq,
+               double *out);
+
+/* [J, dJdv] = nlpObjective(v)   functions/single_shooting.m:137-150
+ * v holds nC*nBasis control coefficients followed by nFree free initial states; FreeInitStates are
+ * 1-based state indices (host array).  x0 is overwritten at FreeInitStates (:146).
+ * host: x0 nS x batch, v (nV+nFree) x batch, J batch, dJdv (nV+nFree) x batch.
+ * device: the same arrays batch-minor ([rows][batch]). */
+int ocs_nlp_objective(ocs_integrator g, ocs_problem p, ocs_control c, int batch, double *x0, const double *v,
+                      int nFree, const int *FreeInitStates, double *J, double *dJdv);
+int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int batch, double *x0,
+                          const double *v, int nFree, const int *FreeInitStates, double *J, double *dJdv,
+                          void *stream);
+
 /* layout helpers: MATLAB (trajectory-major, [batch][cols][rows]) <-> batch-minor ([cols][rows][batch]),
  * device pointers, rows*cols doubles per trajectory. */
 int ocs_to_batch_minor_dev(const double *src, double *dst, int per_traj, int batch, void *stream);

@@ -59,6 +59,22 @@ _SIG = {
     "ocs_compute_adjoints": (C.c_int, [vp, vp, C.c_int, dp, dp, dp, dp]),
     "ocs_compute_states_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
     "ocs_compute_adjoints_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp]),
+    "ocs_rk4inf_create": (C.c_int, [C.POINTER(vp), dp, C.c_int, dp, C.c_int, dp, C.c_int]),
+    "ocs_control_create": (C.c_int, [C.POINTER(vp), C.c_int, dp, C.c_int, C.c_int, C.c_int]),
+    "ocs_control_destroy": (C.c_int, [vp]),
+    "ocs_control_dims": (C.c_int, [vp, ip, ip, ip]),
+    "ocs_control_basis": (C.c_int, [vp, dp]),
+    "ocs_control_points": (C.c_int, [vp, dp]),
+    "ocs_control_compute_u": (C.c_int, [vp, C.c_int, dp, dp]),
+    "ocs_control_compute_dJdv": (C.c_int, [vp, C.c_int, dp, dp]),
+    "ocs_control_compute_u_dev": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "ocs_control_compute_dJdv_dev": (C.c_int, [vp, C.c_int, vp, vp, vp]),
+    "ocs_control_compute_initial_v": (C.c_int, [vp, dp, C.c_int, dp]),
+    "ocs_control_compute_nlp_bounds": (C.c_int, [vp, dp, dp, dp]),
+    "ocs_control_eval_uFunc": (C.c_int, [vp, dp, C.c_int, dp, dp]),
+    "ocs_interp": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp]),
+    "ocs_nlp_objective": (C.c_int, [vp, vp, vp, C.c_int, dp, dp, C.c_int, ip, dp, dp]),
+    "ocs_nlp_objective_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, ip, vp, vp, vp]),
     "ocs_to_batch_minor_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "ocs_to_traj_major_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
 }

@@ -2,198 +2,9 @@
 // validation, host<->device staging and layout conversion around the gfx950 kernels.
 // No compute happens on the host here; if no MI355X is usable every compute entry point
 // fails with OCS_ERR_NO_DEVICE.
-#include "../../include/ocs.h"
-
-#include <hip/hip_runtime.h>
-
-#include <cmath>
-#include <cstdarg>
-#include <cstdio>
-#include <cstring>
-#include <string>
-#include <vector>
-
-#include "ocs_internal.hpp"
+#include "ocs_handles.hpp"
 
 using namespace ocs;
-
-// ------------------------------------------------------------------------------------
-// errors
-// ------------------------------------------------------------------------------------
-static thread_local std::string g_err;
-
-static int fail(int code, const char* fmt, ...) {
-  char buf[512];
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(buf, sizeof(buf), fmt, ap);
-  va_end(ap);
-  g_err = buf;
-  return code;
-}
-#define HIP_TRY(expr)                                                                       \
-  do {                                                                                      \
-    hipError_t e_ = (expr);                                                                 \
-    if (e_ != hipSuccess) return fail(OCS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
-  } while (0)
-#define LAUNCH_TRY(expr)                                                                    \
-  do {                                                                                      \
-    int rc_ = (expr);                                                                       \
-    if (rc_ < 0) return fail(OCS_ERR_UNSUPPORTED, "%s: no kernel for this problem", #expr); \
-    if (rc_ > 0) return fail(OCS_ERR_HIP, "%s: %s", #expr, hipGetErrorString((hipError_t)rc_)); \
-  } while (0)
-#define OCS_TRY(expr)         \
-  do {                        \
-    int rc_ = (expr);         \
-    if (rc_ < 0) return rc_;  \
-  } while (0)
-
-static int require_device() {
-  static int state = 0;  // 0 unknown, 1 ok, -1 none
-  if (state == 0) {
-    int n = 0;
-    hipError_t e = hipGetDeviceCount(&n);
-    state = (e == hipSuccess && n > 0) ? 1 : -1;
-  }
-  if (state < 0)
-    return fail(OCS_ERR_NO_DEVICE, "no HIP device: libocs has no CPU fallback, an MI355X is required");
-  return OCS_OK;
-}
-
-// ------------------------------------------------------------------------------------
-// device buffers
-// ------------------------------------------------------------------------------------
-struct DevBuf {
-  void* p = nullptr;
-  size_t cap = 0;
-  int ensure(size_t bytes) {
-    if (bytes <= cap) return OCS_OK;
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-    HIP_TRY(hipMalloc(&p, bytes));
-    cap = bytes;
-    return OCS_OK;
-  }
-  void release() {
-    if (p) (void)hipFree(p);
-    p = nullptr;
-    cap = 0;
-  }
-  double* d() const { return static_cast<double*>(p); }
-};
-
-// ------------------------------------------------------------------------------------
-// handles
-// ------------------------------------------------------------------------------------
-static unsigned long long g_version_counter = 1;
-
-struct ocs_problem_s {
-  int id = 0, nS = 0, nC = 0;
-  Functor functor = Functor::Logistic;
-  std::vector<double> par;      // functor order
-  std::vector<int> user2func;   // user parameter index -> functor parameter index
-  std::vector<double> bounds;   // nC x 2
-  DevBuf d_ps, d_pb, d_lb, d_ub;
-  unsigned pmask = 0;
-  int pb_batch = 0;
-  unsigned long long version = 0;  // bumps whenever device-visible parameters change
-  bool uploaded = false;
-};
-
-struct ocs_integrator_s {
-  int N = 0;
-  std::vector<double> tspan, t, h;
-  DevBuf d_HT, d_T, d_TC, d_TU, d_REC;
-  bool grid_uploaded = false;
-  unsigned long long tc_version = 0;  // version of the problem TC was built for
-  const ocs_problem_s* tc_prob = nullptr;
-  // state of the last forward pass (the xK contract of RK4Integrator.m:10,32)
-  const double* ck = nullptr;
-  int ck_batch = 0;
-  const ocs_problem_s* ck_prob = nullptr;
-  // staging for the host entry points
-  hipStream_t stream = nullptr;
-  DevBuf d_x0, d_u, d_x, d_J, d_lam, d_dJdu, d_lamT, d_stage, d_ck;
-};
-
-static int upload_problem(ocs_problem_s* p) {
-  if (p->uploaded) return OCS_OK;
-  OCS_TRY(require_device());
-  OCS_TRY(p->d_ps.ensure(sizeof(double) * p->par.size()));
-  HIP_TRY(hipMemcpy(p->d_ps.p, p->par.data(), sizeof(double) * p->par.size(), hipMemcpyHostToDevice));
-  OCS_TRY(p->d_lb.ensure(sizeof(double) * p->nC));
-  OCS_TRY(p->d_ub.ensure(sizeof(double) * p->nC));
-  HIP_TRY(hipMemcpy(p->d_lb.p, p->bounds.data(), sizeof(double) * p->nC, hipMemcpyHostToDevice));
-  HIP_TRY(hipMemcpy(p->d_ub.p, p->bounds.data() + p->nC, sizeof(double) * p->nC, hipMemcpyHostToDevice));
-  p->uploaded = true;
-  return OCS_OK;
-}
-
-static ProblemDesc describe(const ocs_problem_s* p) {
-  ProblemDesc d;
-  d.functor = p->functor;
-  d.nS = p->nS;
-  d.nC = p->nC;
-  d.npar = (int)p->par.size();
-  d.ps = p->d_ps.d();
-  d.pb = p->pmask ? p->d_pb.d() : nullptr;
-  d.pmask = p->pmask;
-  d.lb = p->d_lb.d();
-  d.ub = p->d_ub.d();
-  return d;
-}
-
-static int upload_grid(ocs_integrator_s* g) {
-  if (g->grid_uploaded) return OCS_OK;
-  OCS_TRY(require_device());
-  const int N = g->N;
-  std::vector<double> HT((size_t)4 * N);
-  for (int i = 0; i < N; ++i) {  // the divisions the reference performs per step, done once in IEEE fp64
-    HT[4 * i + 0] = g->h[i];
-    HT[4 * i + 1] = g->h[i] / 2;  // RK4Integrator.m:40
-    HT[4 * i + 2] = g->h[i] / 6;  // :50, :73
-    HT[4 * i + 3] = g->h[i] / 3;  // :77
-  }
-  OCS_TRY(g->d_HT.ensure(sizeof(double) * HT.size()));
-  HIP_TRY(hipMemcpy(g->d_HT.p, HT.data(), sizeof(double) * HT.size(), hipMemcpyHostToDevice));
-  OCS_TRY(g->d_T.ensure(sizeof(double) * g->t.size()));
-  HIP_TRY(hipMemcpy(g->d_T.p, g->t.data(), sizeof(double) * g->t.size(), hipMemcpyHostToDevice));
-  if (!g->stream) HIP_TRY(hipStreamCreate(&g->stream));
-  g->grid_uploaded = true;
-  return OCS_OK;
-}
-
-static GridDesc describe(const ocs_integrator_s* g) {
-  GridDesc d;
-  d.N = g->N;
-  d.HT = g->d_HT.d();
-  d.T = g->d_T.d();
-  d.TC = g->d_TC.d();
-  d.TU = g->d_TU.d();
-  d.REC = g->d_REC.d();
-  return d;
-}
-
-// make sure the time-coefficient table of (g, p) is current; enqueued on `s`
-static int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStream_t s) {
-  OCS_TRY(upload_problem(p));
-  OCS_TRY(upload_grid(g));
-  if (p->pmask && p->pb_batch != batch)
-    return fail(OCS_ERR_SHAPE, "problem has per-trajectory parameters for batch %d, call has batch %d",
-                p->pb_batch, batch);
-  if (g->tc_prob != p || g->tc_version != p->version) {
-    const int ntc = functor_ntc(p->functor, p->nS);
-    const int ntu = functor_ntu(p->functor, p->nS);
-    OCS_TRY(g->d_TC.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * ntc));
-    OCS_TRY(g->d_TU.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * (ntu > 0 ? ntu : 1)));
-    OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)g->N * rec_stride_host(ntc)));
-    LAUNCH_TRY(launch_tcoef(describe(p), describe(g), s));
-    g->tc_prob = p;
-    g->tc_version = p->version;
-  }
-  return OCS_OK;
-}
 
 // ------------------------------------------------------------------------------------
 // library
@@ -201,7 +12,7 @@ static int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStr
 extern "C" {
 
 const char* ocs_version(void) { return "ocs-mi355x 0.1 (gfx950, fp64)"; }
-const char* ocs_last_error(void) { return g_err.c_str(); }
+const char* ocs_last_error(void) { return err_string().c_str(); }
 
 int ocs_device_count(int* count) {
   if (!count) return fail(OCS_ERR_INVALID, "count is NULL");
@@ -259,7 +70,7 @@ int ocs_problem_create(ocs_problem* out, int problem_id, int nS, int nC, const d
     return fail(OCS_ERR_UNSUPPORTED, "no kernel instantiated for nS=%d nC=%d", nS, nC);
   }
   p->bounds.assign(control_bounds, control_bounds + 2 * nC);
-  p->version = g_version_counter++;
+  p->version = next_version();
   *out = p;
   return OCS_OK;
 }
@@ -287,7 +98,7 @@ int ocs_problem_set_batch_params(ocs_problem p, int batch, const int* param_inde
   if (nidx == 0) {  // clear
     p->pmask = 0;
     p->pb_batch = 0;
-    p->version = g_version_counter++;
+    p->version = next_version();
     return OCS_OK;
   }
   if (!param_index || !values || batch < 1 || nidx < 0) return fail(OCS_ERR_INVALID, "bad argument");
@@ -311,7 +122,7 @@ int ocs_problem_set_batch_params(ocs_problem p, int batch, const int* param_inde
   HIP_TRY(hipMemcpy(p->d_pb.p, pb.data(), sizeof(double) * pb.size(), hipMemcpyHostToDevice));
   p->pmask = mask;
   p->pb_batch = batch;
-  p->version = g_version_counter++;
+  p->version = next_version();
   return OCS_OK;
 }
 
@@ -382,8 +193,31 @@ int ocs_rk4_create(ocs_integrator* out, const double* tspan, int npts) {
   return OCS_OK;
 }
 
+/* obj = RK4InfiniteIntegrator(tspan, tspanExtra, uStar)   Integrator/RK4InfiniteIntegrator.m:12-17 */
+int ocs_rk4inf_create(ocs_integrator* out, const double* tspan, int npts, const double* tspanExtra,
+                      int nptsExtra, const double* uStar, int nC) {
+  if (!out || !tspan || !tspanExtra || !uStar) return fail(OCS_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (nC < 1) return fail(OCS_ERR_SHAPE, "uStar needs nC >= 1 entries");
+  ocs_integrator g1 = nullptr, g2 = nullptr;
+  OCS_TRY(ocs_rk4_create(&g1, tspan, npts));
+  int rc = ocs_rk4_create(&g2, tspanExtra, nptsExtra);
+  if (rc < 0) {
+    ocs_integrator_destroy(g1);
+    return rc;
+  }
+  g1->kind = 1;
+  g1->leg2 = g2;
+  g1->ustar.assign(uStar, uStar + nC);
+  *out = g1;
+  return OCS_OK;
+}
+
 int ocs_integrator_destroy(ocs_integrator g) {
   if (!g) return OCS_OK;
+  if (g->leg2) ocs_integrator_destroy(g->leg2);
+  g->d_ustar.release();
+  g->d_lam2.release();
   if (g->stream) (void)hipStreamDestroy(g->stream);
   DevBuf* bufs[] = {&g->d_HT, &g->d_T, &g->d_TC, &g->d_TU, &g->d_REC, &g->d_x0, &g->d_u, &g->d_x, &g->d_J,
                     &g->d_lam, &g->d_dJdu, &g->d_lamT, &g->d_stage, &g->d_ck};
@@ -407,22 +241,42 @@ int ocs_integrator_h(ocs_integrator g, double* h) {
   return OCS_OK;
 }
 
+// one RK4 leg, forward.  ck receives the checkpoints (x itself when the caller wants x).
+static int leg_forward(ocs_integrator_s* g, ocs_problem_s* p, int batch, const double* x0, const double* u,
+                       double* x, double* J, const FwdOpts& o, hipStream_t s) {
+  OCS_TRY(bind_problem(g, p, batch, s));
+  double* ck = x;
+  if (!ck && (g->kind == 1 || o.uconst || g->want_ck)) {
+    // checkpoints go to handle-owned scratch so the adjoint pass can still run
+    OCS_TRY(g->d_ck.ensure(sizeof(double) * (size_t)(p->nS + 1) * (g->N + 1) * batch));
+    ck = g->d_ck.d();
+  }
+  g->ck = nullptr;
+  LAUNCH_TRY(launch_forward(describe(p), describe(g), batch, x0, u, ck, J, o, s));
+  g->ck = ck;
+  g->ck_batch = batch;
+  g->ck_prob = p;
+  return OCS_OK;
+}
+
 int ocs_compute_states_dev(ocs_integrator g, ocs_problem p, int batch, const double* x0, const double* u,
                            double* x, double* J, void* stream) {
   if (!g || !p || !x0 || !u || !J) return fail(OCS_ERR_INVALID, "null argument");
   if (batch < 1) return fail(OCS_ERR_SHAPE, "batch must be >= 1");
   hipStream_t s = (hipStream_t)stream;
-  OCS_TRY(bind_problem(g, p, batch, s));
-  double* ck = x;
-  if (!ck) {  // J-only call: checkpoints go to handle-owned scratch so the adjoint pass can still run
-    OCS_TRY(g->d_ck.ensure(sizeof(double) * (size_t)(p->nS + 1) * (g->N + 1) * batch));
-    ck = g->d_ck.d();
-  }
-  g->ck = nullptr;
-  LAUNCH_TRY(launch_forward(describe(p), describe(g), batch, x0, u, ck, J, s));
-  g->ck = ck;
-  g->ck_batch = batch;
-  g->ck_prob = p;
+  g->want_ck = true;
+  if (g->kind == 0) return leg_forward(g, p, batch, x0, u, x, J, FwdOpts(), s);
+  // RK4InfiniteIntegrator.m:20-24: [x,J1] = leg1(x0,u); [~,J2] = leg2(x(1:end-1,end), uStar); J = J1 + J2
+  if ((int)g->ustar.size() != p->nC) return fail(OCS_ERR_SHAPE, "uStar has %d entries, problem has nC=%d",
+                                                 (int)g->ustar.size(), p->nC);
+  OCS_TRY(leg_forward(g, p, batch, x0, u, x, J, FwdOpts(), s));
+  const double* xT = g->ck + (size_t)g->N * (p->nS + 1) * batch;  // x(1:nS, end): rows are contiguous [nS][B]
+  ocs_integrator_s* g2 = g->leg2;
+  OCS_TRY(g2->d_ck.ensure(sizeof(double) * (size_t)(p->nS + 1) * (g2->N + 1) * batch));
+  FwdOpts o2;
+  o2.uconst = true;
+  o2.Jadd = J;
+  OCS_TRY(leg_forward(g2, p, batch, xT, g->d_ustar.d(), g2->d_ck.d(), J, o2, s));
   return OCS_OK;
 }
 
@@ -434,7 +288,24 @@ int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const d
     return fail(OCS_ERR_ORDER, "compute_adjoints needs compute_states first on the same handle/problem/batch");
   hipStream_t s = (hipStream_t)stream;
   OCS_TRY(bind_problem(g, p, batch, s));
-  LAUNCH_TRY(launch_backward(describe(p), describe(g), batch, g->ck, u, lamT, lam, dJdu, s));
+  BwdOpts o;
+  o.lam0 = g->want_lam0;
+  if (g->kind == 1) {
+    // RK4InfiniteIntegrator.m:27-30: lam2 = leg2.adjoints(uStar); [lam,dJdu] = leg1.adjoints(u, lam2(:,1))
+    if (lamT) return fail(OCS_ERR_INVALID, "RK4InfiniteIntegrator.compute_adjoints takes no lamT");
+    ocs_integrator_s* g2 = g->leg2;
+    if (!g2->ck || g2->ck_prob != p || g2->ck_batch != batch)
+      return fail(OCS_ERR_ORDER, "tail leg has no forward pass");
+    OCS_TRY(bind_problem(g2, p, batch, s));
+    OCS_TRY(g->d_lam2.ensure(sizeof(double) * (size_t)(p->nS + 1) * batch));
+    BwdOpts o2;
+    o2.uconst = true;
+    o2.lam0 = g->d_lam2.d();
+    LAUNCH_TRY(launch_backward(describe(p), describe(g2), batch, g2->ck, g->d_ustar.d(), nullptr, nullptr, nullptr,
+                               o2, s));
+    lamT = g->d_lam2.d();
+  }
+  LAUNCH_TRY(launch_backward(describe(p), describe(g), batch, g->ck, u, lamT, lam, dJdu, o, s));
   return OCS_OK;
 }
 

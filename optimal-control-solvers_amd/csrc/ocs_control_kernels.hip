@@ -1,0 +1,86 @@
+// ocs_control_kernels.hip -- control parametrisations on the device.
+//
+// Reference: every Control class is a fixed basis matrix B (nBasis x nT) with
+//   u = reshape(v, nC, []) * B          (PWLinearControl.m:59-62 and twins)
+//   dJdv = reshape(dJdu * B', [], 1)    (PWLinearControl.m:53-56 and twins)
+// computed as dense products although B is ~98 % zeros for the piecewise bases.  B is shared
+// by the whole batch, so it is kept as a wave-uniform sparse matrix (CSC for u, CSR for dJdv);
+// each (time point, trajectory) / (basis function, trajectory) pair is one thread, terms are
+// accumulated in ascending index order = the order of the reference's dense dot product
+// (the skipped terms are exact zeros).  Batch-minor layouts: v [nBasis][nC][B], u [nT][nC][B].
+#include "ocs_internal.hpp"
+
+namespace ocs {
+
+static inline int hip_rc2(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+// u[j][c][b] = sum_{k in col j} v[row[k]][c][b] * val[k]
+__global__ __launch_bounds__(256) void k_basis_expand(int nT, int nC, int batch, const int* __restrict__ colptr,
+                                                      const int* __restrict__ row, const double* __restrict__ val,
+                                                      const double* __restrict__ v, double* __restrict__ u) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (b >= batch || j >= nT) return;
+  const size_t B = (size_t)batch;
+  const int k0 = colptr[j], k1 = colptr[j + 1];
+  for (int c = 0; c < nC; ++c) {
+    double acc = 0.0;
+    for (int k = k0; k < k1; ++k) acc += v[((size_t)row[k] * nC + c) * B + b] * val[k];
+    u[((size_t)j * nC + c) * B + b] = acc;
+  }
+}
+
+// dJdv[i][c][b] = sum_{k in row i} dJdu[col[k]][c][b] * val[k]
+__global__ __launch_bounds__(256) void k_basis_contract(int nBasis, int nC, int batch, const int* __restrict__ rowptr,
+                                                        const int* __restrict__ col, const double* __restrict__ val,
+                                                        const double* __restrict__ dJdu, double* __restrict__ dJdv) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (b >= batch || i >= nBasis) return;
+  const size_t B = (size_t)batch;
+  const int k0 = rowptr[i], k1 = rowptr[i + 1];
+  for (int c = 0; c < nC; ++c) {
+    double acc = 0.0;
+    for (int k = k0; k < k1; ++k) acc += dJdu[((size_t)col[k] * nC + c) * B + b] * val[k];
+    dJdv[((size_t)i * nC + c) * B + b] = acc;
+  }
+}
+
+// dst[r][b] = src[idx[r]][b]   (gathers rows of a batch-minor array; used for lam(FreeInitStates,1))
+__global__ void k_gather_rows(int nrows, int batch, const int* __restrict__ idx, const double* __restrict__ src,
+                              double* __restrict__ dst) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (b >= batch || r >= nrows) return;
+  dst[(size_t)r * batch + b] = src[(size_t)idx[r] * batch + b];
+}
+// dst[idx[r]][b] = src[r][b]
+__global__ void k_scatter_rows(int nrows, int batch, const int* __restrict__ idx, const double* __restrict__ src,
+                               double* __restrict__ dst) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int r = blockIdx.y;
+  if (b >= batch || r >= nrows) return;
+  dst[(size_t)idx[r] * batch + b] = src[(size_t)r * batch + b];
+}
+
+int launch_basis_expand(int nT, int nC, int batch, const int* colptr, const int* row, const double* val,
+                        const double* v, double* u, hipStream_t s) {
+  k_basis_expand<<<dim3((batch + 255) / 256, nT), dim3(256), 0, s>>>(nT, nC, batch, colptr, row, val, v, u);
+  return hip_rc2(hipGetLastError());
+}
+int launch_basis_contract(int nBasis, int nC, int batch, const int* rowptr, const int* col, const double* val,
+                          const double* dJdu, double* dJdv, hipStream_t s) {
+  k_basis_contract<<<dim3((batch + 255) / 256, nBasis), dim3(256), 0, s>>>(nBasis, nC, batch, rowptr, col, val,
+                                                                             dJdu, dJdv);
+  return hip_rc2(hipGetLastError());
+}
+int launch_gather_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s) {
+  k_gather_rows<<<dim3((batch + 255) / 256, nrows), dim3(256), 0, s>>>(nrows, batch, idx, src, dst);
+  return hip_rc2(hipGetLastError());
+}
+int launch_scatter_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s) {
+  k_scatter_rows<<<dim3((batch + 255) / 256, nrows), dim3(256), 0, s>>>(nrows, batch, idx, src, dst);
+  return hip_rc2(hipGetLastError());
+}
+
+}  // namespace ocs

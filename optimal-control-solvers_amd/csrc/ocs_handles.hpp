@@ -1,0 +1,221 @@
+// ocs_handles.hpp -- private: handle structs, error plumbing and staging helpers shared by
+// the C-ABI translation units (ocs_api.cpp, ocs_control.cpp, ocs_fbs.cpp).
+#pragma once
+#include "../../include/ocs.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "ocs_internal.hpp"
+
+namespace ocs {
+
+// ------------------------------------------------------------------------------------
+// errors
+// ------------------------------------------------------------------------------------
+inline std::string& err_string() {
+  static thread_local std::string s;
+  return s;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  err_string() = buf;
+  return code;
+}
+#define HIP_TRY(expr)                                                                       \
+  do {                                                                                      \
+    hipError_t e_ = (expr);                                                                 \
+    if (e_ != hipSuccess) return fail(OCS_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+  } while (0)
+#define LAUNCH_TRY(expr)                                                                    \
+  do {                                                                                      \
+    int rc_ = (expr);                                                                       \
+    if (rc_ < 0) return fail(OCS_ERR_UNSUPPORTED, "%s: no kernel for this problem", #expr); \
+    if (rc_ > 0) return fail(OCS_ERR_HIP, "%s: %s", #expr, hipGetErrorString((hipError_t)rc_)); \
+  } while (0)
+#define OCS_TRY(expr)         \
+  do {                        \
+    int rc_ = (expr);         \
+    if (rc_ < 0) return rc_;  \
+  } while (0)
+
+inline int require_device() {
+  static int state = 0;  // 0 unknown, 1 ok, -1 none
+  if (state == 0) {
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    state = (e == hipSuccess && n > 0) ? 1 : -1;
+  }
+  if (state < 0)
+    return fail(OCS_ERR_NO_DEVICE, "no HIP device: libocs has no CPU fallback, an MI355X is required");
+  return OCS_OK;
+}
+
+// ------------------------------------------------------------------------------------
+// device buffers
+// ------------------------------------------------------------------------------------
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int ensure(size_t bytes) {
+    if (bytes <= cap) return OCS_OK;
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return OCS_OK;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+  }
+  double* d() const { return static_cast<double*>(p); }
+};
+
+// ------------------------------------------------------------------------------------
+// handles
+// ------------------------------------------------------------------------------------
+inline unsigned long long next_version() {
+  static unsigned long long c = 1;
+  return c++;
+}
+
+}  // namespace ocs
+
+struct ocs_problem_s {
+  using DevBuf = ocs::DevBuf;
+  using Functor = ocs::Functor;
+  int id = 0, nS = 0, nC = 0;
+  Functor functor = Functor::Logistic;
+  std::vector<double> par;      // functor order
+  std::vector<int> user2func;   // user parameter index -> functor parameter index
+  std::vector<double> bounds;   // nC x 2
+  DevBuf d_ps, d_pb, d_lb, d_ub;
+  unsigned pmask = 0;
+  int pb_batch = 0;
+  unsigned long long version = 0;  // bumps whenever device-visible parameters change
+  bool uploaded = false;
+};
+
+struct ocs_integrator_s {
+  using DevBuf = ocs::DevBuf;
+  int kind = 0;  // 0 RK4Integrator, 1 RK4InfiniteIntegrator (then `leg2` and `ustar` are set)
+  ocs_integrator_s* leg2 = nullptr;   // integrator2 of RK4InfiniteIntegrator.m:13-14
+  std::vector<double> ustar;          // uStar (nC)
+  DevBuf d_ustar, d_lam2;             // device uStar [nC]; lam2(:,1) [nAug][B]
+  int N = 0;
+  std::vector<double> tspan, t, h;
+  DevBuf d_HT, d_T, d_TC, d_TU, d_REC;
+  bool grid_uploaded = false;
+  unsigned long long tc_version = 0;  // version of the problem TC was built for
+  const ocs_problem_s* tc_prob = nullptr;
+  bool want_ck = true;          // keep checkpoints of J-only forward passes (adjoint may follow)
+  double* want_lam0 = nullptr;  // if set, the next adjoint pass also writes lam(:,1) here ([nAug][B])
+  // state of the last forward pass (the xK contract of RK4Integrator.m:10,32)
+  const double* ck = nullptr;
+  int ck_batch = 0;
+  const ocs_problem_s* ck_prob = nullptr;
+  // staging for the host entry points
+  hipStream_t stream = nullptr;
+  DevBuf d_x0, d_u, d_x, d_J, d_lam, d_dJdu, d_lamT, d_stage, d_ck;
+};
+
+namespace ocs {
+
+inline int upload_problem(ocs_problem_s* p) {
+  if (p->uploaded) return OCS_OK;
+  OCS_TRY(require_device());
+  OCS_TRY(p->d_ps.ensure(sizeof(double) * p->par.size()));
+  HIP_TRY(hipMemcpy(p->d_ps.p, p->par.data(), sizeof(double) * p->par.size(), hipMemcpyHostToDevice));
+  OCS_TRY(p->d_lb.ensure(sizeof(double) * p->nC));
+  OCS_TRY(p->d_ub.ensure(sizeof(double) * p->nC));
+  HIP_TRY(hipMemcpy(p->d_lb.p, p->bounds.data(), sizeof(double) * p->nC, hipMemcpyHostToDevice));
+  HIP_TRY(hipMemcpy(p->d_ub.p, p->bounds.data() + p->nC, sizeof(double) * p->nC, hipMemcpyHostToDevice));
+  p->uploaded = true;
+  return OCS_OK;
+}
+
+inline ProblemDesc describe(const ocs_problem_s* p) {
+  ProblemDesc d;
+  d.functor = p->functor;
+  d.nS = p->nS;
+  d.nC = p->nC;
+  d.npar = (int)p->par.size();
+  d.ps = p->d_ps.d();
+  d.pb = p->pmask ? p->d_pb.d() : nullptr;
+  d.pmask = p->pmask;
+  d.lb = p->d_lb.d();
+  d.ub = p->d_ub.d();
+  return d;
+}
+
+inline int upload_grid(ocs_integrator_s* g) {
+  if (g->grid_uploaded) return OCS_OK;
+  OCS_TRY(require_device());
+  const int N = g->N;
+  std::vector<double> HT((size_t)4 * N);
+  for (int i = 0; i < N; ++i) {  // the divisions the reference performs per step, done once in IEEE fp64
+    HT[4 * i + 0] = g->h[i];
+    HT[4 * i + 1] = g->h[i] / 2;  // RK4Integrator.m:40
+    HT[4 * i + 2] = g->h[i] / 6;  // :50, :73
+    HT[4 * i + 3] = g->h[i] / 3;  // :77
+  }
+  OCS_TRY(g->d_HT.ensure(sizeof(double) * HT.size()));
+  HIP_TRY(hipMemcpy(g->d_HT.p, HT.data(), sizeof(double) * HT.size(), hipMemcpyHostToDevice));
+  OCS_TRY(g->d_T.ensure(sizeof(double) * g->t.size()));
+  HIP_TRY(hipMemcpy(g->d_T.p, g->t.data(), sizeof(double) * g->t.size(), hipMemcpyHostToDevice));
+  if (!g->stream) HIP_TRY(hipStreamCreate(&g->stream));
+  if (g->kind == 1) {
+    OCS_TRY(g->d_ustar.ensure(sizeof(double) * g->ustar.size()));
+    HIP_TRY(hipMemcpy(g->d_ustar.p, g->ustar.data(), sizeof(double) * g->ustar.size(), hipMemcpyHostToDevice));
+  }
+  g->grid_uploaded = true;
+  return OCS_OK;
+}
+
+inline GridDesc describe(const ocs_integrator_s* g) {
+  GridDesc d;
+  d.N = g->N;
+  d.HT = g->d_HT.d();
+  d.T = g->d_T.d();
+  d.TC = g->d_TC.d();
+  d.TU = g->d_TU.d();
+  d.REC = g->d_REC.d();
+  return d;
+}
+
+// make sure the time-coefficient table of (g, p) is current; enqueued on `s`
+inline int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStream_t s) {
+  OCS_TRY(upload_problem(p));
+  OCS_TRY(upload_grid(g));
+  if (p->pmask && p->pb_batch != batch)
+    return fail(OCS_ERR_SHAPE, "problem has per-trajectory parameters for batch %d, call has batch %d",
+                p->pb_batch, batch);
+  if (g->tc_prob != p || g->tc_version != p->version) {
+    const int ntc = functor_ntc(p->functor, p->nS);
+    const int ntu = functor_ntu(p->functor, p->nS);
+    OCS_TRY(g->d_TC.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * ntc));
+    OCS_TRY(g->d_TU.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * (ntu > 0 ? ntu : 1)));
+    OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)g->N * rec_stride_host(ntc)));
+    LAUNCH_TRY(launch_tcoef(describe(p), describe(g), s));
+    g->tc_prob = p;
+    g->tc_version = p->version;
+  }
+  return OCS_OK;
+}
+
+
+}  // namespace ocs

@@ -32,10 +32,22 @@ struct GridDesc {
 // Device-native layouts (batch-minor): x0 [nS][B], u [2N+1][nC][B], x [N+1][nAug][B],
 // lam [N+1][nAug][B], dJdu [2N+1][nC][B], J [B], lamT [nAug][B].
 int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s);
+struct FwdOpts {
+  bool uconst = false;          // u is a device [nC] vector shared by all grid points and trajectories
+  const double* Jadd = nullptr; // J = Jadd + x(end,end)
+  const int* usel = nullptr;    // per-trajectory control buffer select (fb_sweep)
+  long long udelta = 0;
+};
+struct BwdOpts {
+  bool uconst = false;
+  double* lam0 = nullptr;       // [nAug][B]: lam(:,1)
+  const int* usel = nullptr;
+  long long udelta = 0;
+};
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                   double* x, double* J, hipStream_t s);
+                   double* x, double* J, const FwdOpts& o, hipStream_t s);
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
-                    const double* lamT, double* lam, double* dJdu, hipStream_t s);
+                    const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s);
 // which: 0 F, 1 dFdx_times_vec, 2 dFdu_times_vec; column-major device arrays with k columns.
 int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
                 const double* v, double* out, hipStream_t s);
@@ -44,6 +56,14 @@ int launch_to_batch_minor(const double* src, double* dst, int per, int batch, hi
 int launch_to_traj_major(const double* src, double* dst, int per, int batch, hipStream_t s);
 // number of non-finite entries of v[0..n) is added to *count (device int)
 int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s);
+
+// control bases (ocs_control_kernels.hip); v [nBasis][nC][B], u / dJdu [nT][nC][B]
+int launch_basis_expand(int nT, int nC, int batch, const int* colptr, const int* row, const double* val,
+                        const double* v, double* u, hipStream_t s);
+int launch_basis_contract(int nBasis, int nC, int batch, const int* rowptr, const int* col, const double* val,
+                          const double* dJdu, double* dJdv, hipStream_t s);
+int launch_gather_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
+int launch_scatter_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
 
 // registry queries (host)
 bool functor_supported(Functor f, int nS, int nC);

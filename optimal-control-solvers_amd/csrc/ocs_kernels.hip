@@ -28,6 +28,7 @@ static inline int hip_rc(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 // per-lane vector loads: `__restrict__` on struct members does not reach alias analysis.
 typedef const double __attribute__((address_space(4))) * uniform_ptr;
 __device__ static inline uniform_ptr as_uniform(const double* p) { return (uniform_ptr)p; }
+#define PSU(p) as_uniform(p)
 
 // ---------------------------------------------------------------------------------------
 // time-coefficient table
@@ -123,15 +124,18 @@ struct FwdArgs {
   const double* pb;
   unsigned pmask;
   const double* x0;
-  const double* u;
+  const double* u;      // [2N+1][nC][B]; with UCONST: [nC], the same for every grid point and trajectory
   double* x;
   double* J;
+  const double* Jadd;   // optional [B]: J = Jadd + x(end,end)  (RK4InfiniteIntegrator.m:23  J = J1 + J2)
+  const int* usel;      // optional [B]: trajectory b reads its controls from u + usel[b] * udelta
+  long long udelta;     //              (fb_sweep keeps the old and the new control in two buffers)
 };
 
 // Lanes past the end of the batch are clamped onto the last trajectory: they recompute it and
 // store the same values to the same addresses, which keeps the step body free of exec-mask
 // branches (one basic block per chunk, so the scheduler can hoist the prefetch loads).
-template <class P, int CH, int PF, bool OUT_X>
+template <class P, int CH, int PF, bool OUT_X, bool UCONST>
 __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC;
   using Rec = StepRec<NTC>;
@@ -164,12 +168,19 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
     xo += B;
   }
 
-  const double* up = a.u + b;  // walks u(:,j) row by row
+  const double* up = a.u;  // walks u(:,j) row by row
   double uprev[NC];
+  if (UCONST) {
 #pragma unroll
-  for (int c = 0; c < NC; ++c) {
-    uprev[c] = *up;
-    up += B;
+    for (int c = 0; c < NC; ++c) uprev[c] = PSU(a.u)[c];
+  } else {
+    up += b;
+    if (a.usel) up += (long long)a.usel[b] * a.udelta;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uprev[c] = *up;
+      up += B;
+    }
   }
 
   // one RK4 step, controls at grid points 2i (uA), 2i+1 (uM), 2i+2 (uB)   :36-51
@@ -237,6 +248,15 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
     for (int cc = 0; cc < NC; ++cc) uprev[cc] = src[2 * CH - 1][cc];
   };
 
+  if (UCONST) {  // constant control (tail leg of RK4InfiniteIntegrator.m:15): nothing to load
+    for (int i = 0; i < N; ++i) {
+      const Rec cur = next_rec();
+      step(cur, uprev, uprev, uprev);
+    }
+    a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;
+    if (warm == 1.234567e300) a.J[b] = warm;
+    return;
+  }
   const int nch = N / CH;
   if (nch > 0) load_chunk(ub0);
   int c = 0;
@@ -264,7 +284,7 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) uprev[cc] = uB[cc];
   }
-  a.J[b] = yc;  // J = x(end,end)   :55
+  a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;  // J = x(end,end)   :55
   if (warm == 1.234567e300) a.J[b] = warm;  // never true for a table of step sizes; keeps the sweep alive
 }
 
@@ -282,9 +302,12 @@ struct BwdArgs {
   const double* lamT;  // [nAug][B] or nullptr (default e_last :63-66)
   double* lam;
   double* dJdu;
+  double* lam0;         // optional [nAug][B]: lam(:,1) only (RK4InfiniteIntegrator.m:29, single_shooting.m:149)
+  const int* usel;      // as in FwdArgs
+  long long udelta;
 };
 
-template <class P, int CH, int PF, bool OUT_LAM, bool OUT_DJDU>
+template <class P, int CH, int PF, bool OUT_LAM, bool OUT_DJDU, bool UCONST>
 __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC, NAUG = P::NAUG;
   using Rec = StepRec<NTC>;
@@ -313,7 +336,11 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
   }
   // every array is walked downwards one row (B doubles) at a time, last row of a column first
   double* lo = a.lam + b + ((size_t)(N + 1) * NAUG) * B;      // one past lam(end,N+1)
-  const double* up = a.u + b + ((size_t)(2 * N + 1) * NC) * B;  // one past u(end,2N+1)
+  const double* up = a.u;
+  if (!UCONST) {
+    up += b + ((size_t)(2 * N + 1) * NC) * B;  // one past u(end,2N+1)
+    if (a.usel) up += (long long)a.usel[b] * a.udelta;
+  }
   const double* xp = a.xck + b + ((size_t)N * NAUG) * B;        // x(1,N+1): one past x(end,N)
   double* dp = a.dJdu + b + ((size_t)(2 * N + 1) * NC) * B;     // one past dJdu(end,2N+1)
   if (OUT_LAM) {
@@ -329,8 +356,12 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
   double unext[NC], pend[NC];  // u(:,2i+3) carried from the step above; k1-term of that step
 #pragma unroll
   for (int c = NC - 1; c >= 0; --c) {
-    up -= B;
-    unext[c] = *up;
+    if (UCONST) {
+      unext[c] = PSU(a.u)[c];
+    } else {
+      up -= B;
+      unext[c] = *up;
+    }
     pend[c] = 0.0;
   }
 
@@ -395,7 +426,7 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
     }
   };
 
-  const int nch = N / CH;
+  const int nch = UCONST ? 0 : N / CH;
   Rec rq[PF];
 #pragma unroll
   for (int q = 0; q < PF; ++q) rq[q] = load_rec<NTC>(REC, N - 1 - q > 0 ? N - 1 - q : 0);
@@ -417,15 +448,20 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
       xp -= B;
       xi[k] = *xp;
     }
+    if (UCONST) {
 #pragma unroll
-    for (int c = NC - 1; c >= 0; --c) {
-      up -= B;
-      uM[c] = *up;
-    }
+      for (int c = 0; c < NC; ++c) uA[c] = uM[c] = unext[c];
+    } else {
 #pragma unroll
-    for (int c = NC - 1; c >= 0; --c) {
-      up -= B;
-      uA[c] = *up;
+      for (int c = NC - 1; c >= 0; --c) {
+        up -= B;
+        uM[c] = *up;
+      }
+#pragma unroll
+      for (int c = NC - 1; c >= 0; --c) {
+        up -= B;
+        uA[c] = *up;
+      }
     }
     const Rec cur = next_rec();
     step(cur, xi, uA, uM, unext);
@@ -480,9 +516,15 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
       *dp = pend[cc];  // left end point :101-102
     }
   }
+  if (a.lam0) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) a.lam0[(size_t)k * B + b] = lam[k];
+    a.lam0[(size_t)NS * B + b] = lamc;
+  }
   if (warm == 1.234567e300) {  // never true; keeps the table sweep alive
     if (OUT_DJDU) *dp = warm;
     if (OUT_LAM) *lo = warm;
+    if (a.lam0) a.lam0[b] = warm;
   }
 }
 
@@ -605,35 +647,40 @@ constexpr int kChunk = 4;
 constexpr int kPF = OCS_PF;  // step records in flight
 
 template <class P>
-static void run_forward(const FwdArgs& a, hipStream_t s) {
+static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
   const dim3 grid((a.batch + 63) / 64), block(64);
-  if (a.x)
-    k_forward<P, kChunk, kPF, true><<<grid, block, 0, s>>>(a);
+  if (uconst)
+    k_forward<P, kChunk, kPF, true, true><<<grid, block, 0, s>>>(a);
+  else if (a.x)
+    k_forward<P, kChunk, kPF, true, false><<<grid, block, 0, s>>>(a);
   else
-    k_forward<P, kChunk, kPF, false><<<grid, block, 0, s>>>(a);
+    k_forward<P, kChunk, kPF, false, false><<<grid, block, 0, s>>>(a);
 }
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                   double* x, double* J, hipStream_t s) {
-  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J};
-  OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, s));
+                   double* x, double* J, const FwdOpts& o, hipStream_t s) {
+  if (o.uconst && !x) return -1;
+  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.usel, o.udelta};
+  OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, o.uconst, s));
   return hip_rc(hipGetLastError());
 }
 
 template <class P>
-static void run_backward(const BwdArgs& a, hipStream_t s) {
+static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
   const dim3 grid((a.batch + 63) / 64), block(64);
-  if (a.lam && a.dJdu)
-    k_backward<P, kChunk, kPF, true, true><<<grid, block, 0, s>>>(a);
+  if (uconst)
+    k_backward<P, kChunk, kPF, false, false, true><<<grid, block, 0, s>>>(a);
+  else if (a.lam && a.dJdu)
+    k_backward<P, kChunk, kPF, true, true, false><<<grid, block, 0, s>>>(a);
   else if (a.lam)
-    k_backward<P, kChunk, kPF, true, false><<<grid, block, 0, s>>>(a);
+    k_backward<P, kChunk, kPF, true, false, false><<<grid, block, 0, s>>>(a);
   else
-    k_backward<P, kChunk, kPF, false, true><<<grid, block, 0, s>>>(a);
+    k_backward<P, kChunk, kPF, false, true, false><<<grid, block, 0, s>>>(a);
 }
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
-                    const double* lamT, double* lam, double* dJdu, hipStream_t s) {
-  if (!lam && !dJdu) return -1;
-  const BwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu};
-  OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, s));
+                    const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
+  if (o.uconst ? (lam || dJdu || !o.lam0) : (!lam && !dJdu)) return -1;
+  const BwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, o.lam0, o.usel, o.udelta};
+  OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, o.uconst, s));
   return hip_rc(hipGetLastError());
 }
 

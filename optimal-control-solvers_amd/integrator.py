@@ -44,6 +44,9 @@ class RK4Integrator(Integrator):
         self.tspan = _f(tspan).ravel()
         h = C.c_void_p()
         check(lib.ocs_rk4_create(C.byref(h), _p(self.tspan), self.tspan.size))
+        self._finish_init(h)
+
+    def _finish_init(self, h):
         self._h = h
         n = C.c_int()
         check(lib.ocs_integrator_nsteps(h, C.byref(n)))
@@ -107,3 +110,20 @@ class RK4Integrator(Integrator):
         check(lib.ocs_compute_adjoints_dev(self._h, prob._h, B, _dptr(u), _dptr(lamT), _dptr(lam),
                                            _dptr(dJdu), _stream()))
         return lam, dJdu
+
+
+class RK4InfiniteIntegrator(RK4Integrator):
+    """Integrator/RK4InfiniteIntegrator.m:12-30: RK4 on tspan, then a tail leg on tspanExtra under
+    the constant control uStar; J = J1 + J2, terminal adjoint of leg 1 = lam2(:,1)."""
+
+    def __init__(self, tspan, tspanExtra, uStar):
+        self.tspan = _f(tspan).ravel()
+        self.tspanExtra = _f(tspanExtra).ravel()
+        self.uStar = _f(np.atleast_1d(uStar)).ravel()
+        h = C.c_void_p()
+        check(lib.ocs_rk4inf_create(C.byref(h), _p(self.tspan), self.tspan.size, _p(self.tspanExtra),
+                                    self.tspanExtra.size, _p(self.uStar), self.uStar.size))
+        self._finish_init(h)
+
+    def compute_adjoints(self, prob, u, nargout=2):
+        return super().compute_adjoints(prob, u, None, nargout)

@@ -1,0 +1,33 @@
+"""vectorInterpolant / heval (reference: functions/vectorInterpolant.m, functions/heval.m).
+
+The solvers return sample arrays; this wrapper turns (grid, samples, method) into the callable
+t (1 x k) -> n x k that the reference's soln.x / soln.lam / soln.u are.  Evaluation is the
+library's host-side ocs_interp (linear / previous / pchip with MATLAB's slope rule)."""
+from __future__ import annotations
+
+import numpy as np
+
+from ._lib import check, lib
+from .problem import _f, _p
+
+_METHODS = {"linear": 0, "previous": 2, "pchip": 3}
+
+
+def vectorInterpolant(x, v, interpType):
+    x = _f(x).ravel().copy()
+    v = np.array(np.atleast_2d(np.asarray(v, dtype=np.float64)), order="F", copy=True)
+    method = _METHODS[interpType]
+    nComp = v.shape[0]
+
+    def fInterp(t):
+        t = _f(np.atleast_1d(t)).ravel()
+        out = np.empty((nComp, t.size), order="F")
+        check(lib.ocs_interp(method, nComp, x.size, _p(x), _p(v), t.size, _p(t), _p(out)))
+        return out
+
+    return fInterp
+
+
+def heval(func, tspan, components):
+    """functions/heval.m:1-6 (components are 0-based here)."""
+    return func(tspan)[components, :]

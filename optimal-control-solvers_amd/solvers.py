@@ -1,0 +1,119 @@
+"""Solver drivers above the hot path (reference: functions/single_shooting.m).
+
+`nlp_objective` is the composition v -> (J, dJdv) that fmincon calls (single_shooting.m:137-150);
+it is batch-aware and runs entirely on the GPU.  `single_shooting` keeps the reference's call
+signature and returns the same `soln` fields; MATLAB's fmincon('sqp') is a toolbox dependency that
+does not exist here, so the outer NLP iteration is scipy's SLSQP (also an SQP method) on the host --
+iterates differ from fmincon's, the optimum does not (scope)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, lib
+from .control import PWLinearControl
+from .integrator import RK4Integrator, _dptr, _stream
+from .interp import vectorInterpolant
+from .problem import _f, _p
+
+
+def _fis(FreeInitStates):
+    n = len(FreeInitStates)
+    arr = (C.c_int * max(n, 1))(*[int(k) for k in FreeInitStates])
+    return n, arr
+
+
+def nlp_objective(integrator, prob, control, x0, v, FreeInitStates=()):
+    """[J, dJdv] = nlpObjective(v)   single_shooting.m:137-150.
+    x0: nS [x batch]; v: (nC*nBasis + nFree) [x batch]; FreeInitStates are 1-based like MATLAB.
+    Returns (J, dJdv, x0_after)."""
+    v = np.asarray(v, dtype=np.float64)
+    batched = v.ndim == 2
+    batch = v.shape[1] if batched else 1
+    nFree, fis = _fis(FreeInitStates)
+    nV = control.nControls * control.nBasis + nFree
+    v = _f(v, (nV, batch))
+    x0 = np.array(_f(x0, (prob.nS, batch)), order="F", copy=True)
+    J = np.empty(batch)
+    dJdv = np.empty((nV, batch), order="F")
+    status = check(lib.ocs_nlp_objective(integrator._h, prob._h, control._h, batch, _p(x0), _p(v), nFree, fis,
+                                         _p(J), _p(dJdv)))
+    integrator.status = status
+    if batched:
+        return J, dJdv, x0
+    return float(J[0]), dJdv[:, 0], x0[:, 0]
+
+
+def nlp_objective_dev(integrator, prob, control, x0, v, FreeInitStates=(), J=None, dJdv=None):
+    """device, batch-minor: x0 [nS][B] (overwritten at FreeInitStates), v [nV][B] -> J [B], dJdv [nV][B]."""
+    B = v.shape[-1]
+    nFree, fis = _fis(FreeInitStates)
+    if J is None:
+        J = torch.empty(B, dtype=torch.float64, device=v.device)
+    if dJdv is None:
+        dJdv = torch.empty_like(v)
+    check(lib.ocs_nlp_objective_dev(integrator._h, prob._h, control._h, B, _dptr(x0), _dptr(v), nFree, fis,
+                                    _dptr(J), _dptr(dJdv), _stream()))
+    return J, dJdv
+
+
+def single_shooting(prob, x0, tspan, nCONTROL_PTS, **kw):
+    """soln = single_shooting(prob, x0, tspan, nCONTROL_PTS, Name, Value, ...)   single_shooting.m:1-130.
+    Name/value options and defaults as in :19-30 (TolX 1e-5, TolFun 3e-4, Algorithm 'sqp',
+    Reporting, Control, Integrator, u0, FreeInitStates, FreeStateBounds)."""
+    from scipy.optimize import minimize
+
+    opt = dict(TolX=1e-5, TolFun=3e-4, Algorithm="sqp", Reporting=False, DerivativeCheck="off", Control=None,
+               Integrator=None, u0=0.0, FreeInitStates=(), FreeStateBounds=None, MaxIter=400)
+    unknown = set(kw) - set(opt)
+    if unknown:
+        raise TypeError(f"unknown option(s): {sorted(unknown)}")
+    opt.update(kw)
+    tspan = _f(tspan).ravel()
+    nCONTROLS = prob.ControlBounds.shape[0]
+    MinMax = getattr(prob, "MinMax", "Min")                                     # :11-15
+    FreeInitStates = [int(k) for k in opt["FreeInitStates"]]
+    nFREE = len(FreeInitStates)
+    integrator = opt["Integrator"] or RK4Integrator(tspan)                       # :41-45
+    control = opt["Control"] or PWLinearControl(integrator.t, nCONTROL_PTS, nCONTROLS)  # :48-52
+    x0 = np.array(_f(x0).ravel(), copy=True)
+    u0 = np.minimum(prob.ControlBounds[:, 1], np.maximum(prob.ControlBounds[:, 0],
+                                                         np.broadcast_to(np.asarray(opt["u0"], dtype=np.float64).ravel(),
+                                                                         (nCONTROLS,)) if np.size(opt["u0"]) in (1, nCONTROLS)
+                                                         else np.asarray(opt["u0"], dtype=np.float64).ravel()))  # :56
+    v0 = control.compute_initial_v(u0)                                           # :82-86
+    if nFREE:
+        v0 = np.concatenate([v0, x0[np.array(FreeInitStates) - 1]])
+    bounds = None
+    if hasattr(control, "compute_nlp_bounds"):                                   # :88-97
+        Lb, Ub = control.compute_nlp_bounds(prob.ControlBounds)
+        if nFREE:
+            fsb = _f(opt["FreeStateBounds"], (nFREE, 2))
+            Lb, Ub = np.concatenate([Lb, fsb[:, 0]]), np.concatenate([Ub, fsb[:, 1]])
+        bounds = list(zip(Lb, Ub))
+
+    hist = []
+
+    def fun(v):                                                                  # nlpObjective :137-150
+        J, dJdv, x0n = nlp_objective(integrator, prob, control, x0, v, FreeInitStates)
+        hist.append(J)
+        return J, dJdv
+
+    res = minimize(fun, v0, jac=True, method="SLSQP", bounds=bounds,
+                   options={"ftol": opt["TolFun"] * 1e-3, "maxiter": opt["MaxIter"], "disp": bool(opt["Reporting"])})
+    vOpt = res.x
+    soln = {"J": -res.fun if MinMax == "Max" else res.fun}                       # :117-119
+    nV = vOpt.size - nFREE
+    uOpt = control.compute_u(vOpt[:nV])                                          # :121
+    if nFREE:
+        x0[np.array(FreeInitStates) - 1] = vOpt[nV:]                             # :122-124
+    xOpt, _ = integrator.compute_states(prob, x0, uOpt)                          # :125
+    lamOpt = integrator.compute_adjoints(prob, uOpt, nargout=1)                  # :126
+    soln["u"] = control.compute_uFunc(vOpt[:nV])                                 # :128
+    soln["x"] = vectorInterpolant(tspan, xOpt[:-1, :], "pchip")                  # :129
+    soln["lam"] = vectorInterpolant(tspan, lamOpt[:-1, :], "pchip")              # :130
+    soln["_v"], soln["_nfev"], soln["_message"] = vOpt, res.nfev, res.message
+    return soln

@@ -1,0 +1,169 @@
+"""GPU parity of the control bases, the single_shooting objective/gradient (A8) and
+RK4InfiniteIntegrator (A5) against the CPU oracle, through the C-ABI.  Tolerance 1e-12 relative
+(fp64, FMA contraction + device exp); dJdv sums ~2000 terms, checked against max(1,|ref|)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = {"c": 1.5, "m": 3.0, "r": 0.05}
+BOUNDS = [[0.0, 1.0]]
+RTOL = 1e-12
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def ocs():
+    import torch
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.mark.parametrize("kind,nB,nC", [("PWLinearControl", 21, 1), ("PWLinearControl", 5, 3), ("PWConstantControl", 10, 2),
+                                        ("ChebyshevControl", 16, 1), ("ChebyshevControl", 3, 2)])
+def test_compute_u_and_dJdv(ocs, oracle, kind, nB, nC):
+    t = oracle.RK4Integrator(oracle.linspace(0, 10, 201)).t
+    cg, co = getattr(ocs, kind)(t, nB, nC), getattr(oracle, kind)(t, nB, nC)
+    rng = np.random.default_rng(1)
+    batch = 70
+    v = rng.normal(size=(nC * nB, batch))
+    d = rng.normal(size=(nC, t.size, batch))
+    u = cg.compute_u(v)
+    dv = cg.compute_dJdv(d)
+    for b in (0, 33, 69):
+        assert relerr(u[:, :, b], co.compute_u(v[:, b])) < 1e-14
+        assert relerr(dv[:, b], co.compute_dJdv(d[:, :, b])) < 1e-13
+    # batch = 1 keeps the reference's shapes
+    assert cg.compute_u(v[:, 0]).shape == (nC, t.size) and cg.compute_dJdv(d[:, :, 0]).shape == (nC * nB,)
+
+
+def test_backprop_test_script(ocs, oracle):
+    """tests/backprop_test.m:5-43, seeded: adjoint gradient vs forward differences (eps = 1e-4); the 21
+    perturbed candidates + the base point run as ONE batch of 22."""
+    N, nPts, eps = 500, 21, 1e-4
+    tspan = oracle.linspace(0, 10, N + 1)
+    prob, integ = ocs.TestOCProblem(P, BOUNDS), ocs.RK4Integrator(tspan)
+    ctrl = ocs.PWLinearControl(integ.t, nPts, 1)
+    v = 0.5 + 0.5 * np.random.default_rng(20260404).random(nPts)
+    V = np.tile(v[:, None], (1, nPts + 1))
+    V[np.arange(nPts), np.arange(1, nPts + 1)] += eps
+    J, dJdv, _ = ocs.nlp_objective(integ, prob, ctrl, np.ones((1, nPts + 1)), V)
+    fd = (J[1:] - J[0]) / eps
+    assert np.max(np.abs(fd - dJdv[:, 0])) < 1e-3
+    po, go = oracle.TestOCProblem(P, BOUNDS), oracle.RK4Integrator(tspan)
+    Jo, do, _ = oracle.nlp_objective(go, po, oracle.PWLinearControl(go.t, nPts, 1), [1.0], v)
+    assert abs(J[0] - Jo) < RTOL * abs(Jo) and relerr(dJdv[:, 0], do) < RTOL
+
+
+@pytest.mark.parametrize("kind,nB", [("PWLinearControl", 101), ("PWConstantControl", 50), ("ChebyshevControl", 16)])
+def test_nlp_objective_matches_oracle(ocs, oracle, kind, nB):
+    nS, N, batch = 2, 300, 66
+    m = [3.0, 2.5]
+    tspan = oracle.linspace(0, 10, N + 1)
+    pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    cg, co = getattr(ocs, kind)(g.t, nB, 1), getattr(oracle, kind)(go.t, nB, 1)
+    rng = np.random.default_rng(3)
+    if kind == "ChebyshevControl":  # SURVEY BL-4 candidates
+        V = 0.05 * rng.normal(size=(nB, batch)) / np.arange(1, nB + 1)[:, None]
+        V[0] += 0.4
+    else:
+        V = rng.uniform(0.05, 0.45, (nB, batch))
+    x0 = rng.uniform(0.9, 2.0, (nS, batch))
+    J, dJdv, _ = ocs.nlp_objective(g, pg, cg, x0, V)
+    for b in (0, 1, 64, 65):
+        Jo, do, _ = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b])
+        assert abs(J[b] - Jo) < RTOL * abs(Jo)
+        assert relerr(dJdv[:, b], do) < RTOL
+
+
+def test_free_initial_states(ocs, oracle):
+    # single_shooting.m:144-149: v carries x0(FreeInitStates); dJdv gets lam(FreeInitStates,1)
+    m = [3.0, 2.0, 2.5]
+    tspan = oracle.linspace(0, 5, 101)
+    pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    cg, co = ocs.PWLinearControl(g.t, 6, 1), oracle.PWLinearControl(go.t, 6, 1)
+    rng = np.random.default_rng(4)
+    batch = 5
+    V = np.vstack([rng.uniform(0.1, 0.4, (6, batch)), rng.uniform(1.0, 2.0, (2, batch))])
+    x0 = np.ones((3, batch))
+    J, dJdv, x0n = ocs.nlp_objective(g, pg, cg, x0, V, FreeInitStates=[3, 1])
+    for b in range(batch):
+        Jo, do, x0o = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b], FreeInitStates=[3, 1])
+        assert abs(J[b] - Jo) < RTOL * abs(Jo) and relerr(dJdv[:, b], do) < RTOL
+        assert np.array_equal(x0n[:, b], x0o) and x0n[2, b] == V[6, b] and x0n[0, b] == V[7, b]
+
+
+def test_infinite_integrator(ocs, oracle):
+    # RK4InfiniteIntegrator.m:12-30 with the tail under u* of the equilibrium (solve_test_problem.m:28-33)
+    us = 0.72336878009798256
+    tspan, tx = oracle.linspace(0, 10, 201), oracle.linspace(10, 20, 151)
+    pg, po = ocs.TestOCProblem(P, BOUNDS), oracle.TestOCProblem(P, BOUNDS)
+    gi, go = ocs.RK4InfiniteIntegrator(tspan, tx, [us]), oracle.RK4InfiniteIntegrator(tspan, tx, [us])
+    assert np.array_equal(gi.t, go.t)
+    rng = np.random.default_rng(6)
+    batch = 67
+    u = rng.uniform(0, 1, (1, 401, batch))
+    x0 = rng.uniform(0.5, 2.5, (1, batch))
+    x, J = gi.compute_states(pg, x0, u)
+    lam, dJdu = gi.compute_adjoints(pg, u)
+    for b in (0, 1, 65, 66):
+        xo, Jo = go.compute_states(po, x0[:, b], u[:, :, b])
+        lamo, do = go.compute_adjoints(po, u[:, :, b])
+        assert relerr(x[:, :, b], xo) < RTOL and abs(J[b] - Jo) < RTOL * abs(Jo)
+        assert relerr(lam[:, :, b], lamo) < RTOL and relerr(dJdu[:, :, b], do) < RTOL
+    # as the Integrator of the shooting objective (solve_test_problem.m:38-39, commented out there)
+    cg, co = ocs.PWLinearControl(gi.t, 11, 1), oracle.PWLinearControl(go.t, 11, 1)
+    V = rng.uniform(0.2, 0.9, (11, 3))
+    J, dJdv, _ = ocs.nlp_objective(gi, pg, cg, np.ones((1, 3)), V)
+    for b in range(3):
+        Jo, do, _ = oracle.nlp_objective(go, po, co, [1.0], V[:, b])
+        assert abs(J[b] - Jo) < RTOL * abs(Jo) and relerr(dJdv[:, b], do) < RTOL
+
+
+def test_device_objective_bl4_shape(ocs, oracle):
+    """BASELINE config 4 shape (Chebyshev-16 objective+gradient) on device buffers, reduced batch."""
+    import torch
+    N, nB, batch = 1000, 16, 512
+    tspan = oracle.linspace(0, 10, N + 1)
+    pg, po = ocs.TestOCProblem(P, BOUNDS), oracle.TestOCProblem(P, BOUNDS)
+    g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    cg, co = ocs.ChebyshevControl(g.t, nB, 1), oracle.ChebyshevControl(go.t, nB, 1)
+    rng = np.random.default_rng(20260403)
+    V = 0.05 * rng.normal(size=(nB, batch)) / np.arange(1, nB + 1)[:, None]
+    V[0] += 0.5
+    dev = torch.device("cuda:0")
+    vd = torch.tensor(V, device=dev)                   # [nV][B]
+    x0d = torch.ones((1, batch), dtype=torch.float64, device=dev)
+    Jd, gd = ocs.nlp_objective_dev(g, pg, cg, x0d, vd)
+    torch.cuda.synchronize()
+    Jh, gh = Jd.cpu().numpy(), gd.cpu().numpy()
+    for b in (0, 255, 511):
+        Jo, do, _ = oracle.nlp_objective(go, po, co, [1.0], V[:, b])
+        assert abs(Jh[b] - Jo) < RTOL * abs(Jo) and relerr(gh[:, b], do) < RTOL
+
+
+def test_single_shooting_end_to_end(ocs, oracle):
+    """tests/solve_test_problem.m:5-39 (BL-1 plumbing): T=10, 500 steps, 101 control points, u0 = u*.
+    fmincon is not available; the SLSQP stand-in must reach the same optimum as the same optimiser
+    driven by the CPU oracle, and the optimal control must sit on the turnpike u* in mid-horizon."""
+    from scipy.optimize import minimize
+    us = 0.72336878009798256
+    tspan = oracle.linspace(0, 10, 501)
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    soln = ocs.single_shooting(prob, [1.0], tspan, 101, u0=us)
+    assert set(("J", "u", "x", "lam")) <= set(soln)
+    po, go = oracle.TestOCProblem(P, BOUNDS), oracle.RK4Integrator(tspan)
+    co = oracle.PWLinearControl(go.t, 101, 1)
+    res = minimize(lambda v: oracle.nlp_objective(go, po, co, [1.0], v)[:2], np.full(101, us), jac=True,
+                   method="SLSQP", bounds=[(0.0, 1.0)] * 101, options={"ftol": 3e-7, "maxiter": 400})
+    assert abs(soln["J"] - res.fun) < 1e-6 * abs(res.fun)
+    tq = np.array([4.0, 5.0, 6.0])
+    assert np.max(np.abs(soln["u"](tq) - us)) < 2e-2
+    assert np.max(np.abs(soln["x"](tq) - 2.7355691886341361)) < 2e-2
+    assert soln["x"](np.array([0.0]))[0, 0] == 1.0 and soln["lam"](tq).shape == (1, 3)

@@ -1,0 +1,69 @@
+"""CPU tests of the product's host-side logic (no GPU compute): basis matrices, initial v,
+NLP bounds, uFunc and vectorInterpolant sampling of libocs against the CPU oracle."""
+import numpy as np
+import pytest
+
+
+@pytest.fixture(scope="module")
+def ocs():
+    import __graft_entry__ as g
+    g.build()
+    return g.load_package()
+
+
+def _grid(oracle, N=500, T=10.0):
+    return oracle.RK4Integrator(oracle.linspace(0.0, T, N + 1)).t
+
+
+def test_basis_matrices_bitwise_equal_to_oracle(ocs, oracle):
+    t = _grid(oracle)
+    for cls, ocl, n in ((ocs.PWLinearControl, oracle.PWLinearControl, 101),
+                        (ocs.PWLinearControl, oracle.PWLinearControl, 2),
+                        (ocs.PWConstantControl, oracle.PWConstantControl, 50),
+                        (ocs.PWConstantControl, oracle.PWConstantControl, 1),
+                        (ocs.ChebyshevControl, oracle.ChebyshevControl, 16),
+                        (ocs.ChebyshevControl, oracle.ChebyshevControl, 1)):
+        a, b = cls(t, n, 2), ocl(t, n, 2)
+        assert np.array_equal(a.B, b.B), (cls.__name__, n)
+        assert np.array_equal(a._pts, b._pts)
+    # non-uniform integrator grid
+    tn = oracle.RK4Integrator(np.sort(np.concatenate([[0, 3.0], np.random.default_rng(0).uniform(0, 3, 30)]))).t
+    assert np.array_equal(ocs.PWLinearControl(tn, 7, 1).B, oracle.PWLinearControl(tn, 7, 1).B)
+
+
+def test_initial_v_bounds_ufunc(ocs, oracle):
+    t = _grid(oracle, 40, 4.0)
+    rng = np.random.default_rng(2)
+    for cls, ocl, n in ((ocs.PWLinearControl, oracle.PWLinearControl, 9), (ocs.PWConstantControl, oracle.PWConstantControl, 8),
+                        (ocs.ChebyshevControl, oracle.ChebyshevControl, 6)):
+        a, b = cls(t, n, 2), ocl(t, n, 2)
+        assert np.array_equal(a.compute_initial_v([0.25, 0.5]), b.compute_initial_v([0.25, 0.5]))
+        v = rng.normal(size=2 * n)
+        tq = np.concatenate([t, rng.uniform(t[0], t[-1], 50)])
+        assert np.array_equal(a.compute_uFunc(v)(tq), b.compute_uFunc(v)(tq))
+    a, b = ocs.PWLinearControl(t, 9, 2), oracle.PWLinearControl(t, 9, 2)
+    bounds = [[0.0, 1.0], [-2.0, 3.0]]
+    for x, y in zip(a.compute_nlp_bounds(bounds), b.compute_nlp_bounds(bounds)):
+        assert np.array_equal(x, y)
+    full = rng.normal(size=18)
+    assert np.array_equal(a.compute_initial_v(full), full)
+    with pytest.raises(ocs.OcsError):
+        a.compute_initial_v([1.0, 2.0, 3.0])
+    assert not hasattr(ocs.ChebyshevControl(t, 4, 1), "compute_nlp_bounds")  # ChebyshevControl.m has none
+    with pytest.raises(ocs.OcsError):
+        ocs.PWLinearControl(t, 1, 1)
+
+
+def test_vector_interpolant_matches_oracle(ocs, oracle):
+    rng = np.random.default_rng(5)
+    x = np.sort(rng.uniform(0, 5, 30))
+    v = np.vstack([np.sin(2 * x), np.cumsum(rng.normal(size=30)), np.where(x > 2, 1.0, 0.0)])
+    q = np.concatenate([x, rng.uniform(x[0], x[-1], 200)])
+    for name, m in (("pchip", oracle.INTERP_PCHIP), ("linear", oracle.INTERP_LINEAR), ("previous", oracle.INTERP_PREVIOUS)):
+        got = ocs.vectorInterpolant(x, v, name)(q)
+        ref = oracle.vector_interp(x, v, m, q)
+        assert np.array_equal(got, ref), name
+    one = ocs.vectorInterpolant(x, v[0], "pchip")(q)  # nCOMPONENTS == 1 branch of vectorInterpolant.m:3-4
+    assert one.shape == (1, q.size) and np.array_equal(one[0], got[0] * 0 + ocs.vectorInterpolant(x, v[:1], "pchip")(q)[0])
+    assert np.array_equal(ocs.heval(ocs.vectorInterpolant(x, v, "linear"), q, [2, 0]),
+                          oracle.vector_interp(x, v, oracle.INTERP_LINEAR, q)[[2, 0]])
