@@ -157,6 +157,39 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
                           const double *v, int nFree, const int *FreeInitStates, double *J, double *dJdv,
                           void *stream);
 
+/* ---- forward-backward sweep (functions/fb_sweep.m, compute_x_lam.m, compute_x_lam_J.m) ----
+ * Gen-1 drivers run on a Gen-2 OCProblem through the adapter stateRHS = F(1:nS), objective = F(end),
+ * adjointRHS = -dFdx_times_vec(t,[x;0],u,[lam;1])(1:nS), ControlChar = clamp(argzero dFdu_times_vec(...))
+ * (make_from_symbolic.m:11-23,111).  odevr7 is replaced by RK4 on the grid of `g` (an RK4Integrator),
+ * x(t)/lam(t) are pchip interpolants of the node values as in compute_x_lam.m:9,14. */
+typedef struct ocs_fbs_options {
+  double uRelTol;  /* fb_sweep.m:16 */
+  double uAbsTol;  /* :17 */
+  int nSWEEPS;     /* :20 */
+  int nERROR_PTS;  /* :21 */
+  int nINTERP_PTS; /* :22 */
+} ocs_fbs_options;
+int ocs_fbs_default_options(ocs_fbs_options *o);
+/* [x, lam(, J)] = compute_x_lam(_J)(prob, x0, tspan, u, RelTol, AbsTol)   compute_x_lam.m:1-19, compute_x_lam_J.m:1-21
+ * host: x0 nS x batch, ugrid nC x (2N+1) x batch (u sampled on the grid) -> x, lam nS x (N+1) x batch, J batch or NULL */
+int ocs_compute_x_lam(ocs_integrator g, ocs_problem p, int batch, const double *x0, const double *ugrid,
+                      double *x, double *lam, double *J);
+/* device: xaug [N+1][nAug][batch] (states + running objective), lam [N+1][nS][batch] */
+int ocs_compute_x_lam_dev(ocs_integrator g, ocs_problem p, int batch, const double *x0, const double *ugrid,
+                          double *xaug, double *lam, double *J, void *stream);
+/* soln = fb_sweep(prob, x0, tspan, options)   fb_sweep.m:1-126
+ * u0grid / u0err: the initial control sampled on the 2N+1 grid and on linspace(T0,TF,nERROR_PTS), or both
+ * NULL for the default lower bound (:23).  sweeps[b] = sweep index at which instance b converged, 0 if it
+ * never did (the reference then returns an empty struct, :77).  maxChange (nSWEEPS x batch, may be NULL)
+ * holds the "Normalized change in u" of :109 per sweep (NaN where not run).  uInterp = soln.u sampled on
+ * linspace(T0,TF,nINTERP_PTS) (:123).  Returns OCS_NUM_NOT_CONVERGED if any instance did not converge. */
+int ocs_fb_sweep(ocs_integrator g, ocs_problem p, int batch, const double *x0, const ocs_fbs_options *opt,
+                 const double *u0grid, const double *u0err, double *x, double *lam, double *uInterp, double *J,
+                 int *sweeps, double *maxChange);
+int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double *x0, const ocs_fbs_options *opt,
+                     const double *u0grid, const double *u0err, double *xaug, double *lam, double *uInterp,
+                     double *J, int *sweeps, double *maxChange, void *stream);
+
 /* layout helpers: MATLAB (trajectory-major, [batch][cols][rows]) <-> batch-minor ([cols][rows][batch]),
  * device pointers, rows*cols doubles per trajectory. */
 int ocs_to_batch_minor_dev(const double *src, double *dst, int per_traj, int batch, void *stream);

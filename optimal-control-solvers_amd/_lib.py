@@ -75,6 +75,11 @@ _SIG = {
     "ocs_interp": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp]),
     "ocs_nlp_objective": (C.c_int, [vp, vp, vp, C.c_int, dp, dp, C.c_int, ip, dp, dp]),
     "ocs_nlp_objective_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, ip, vp, vp, vp]),
+    "ocs_fbs_default_options": (C.c_int, [vp]),
+    "ocs_compute_x_lam": (C.c_int, [vp, vp, C.c_int, dp, dp, dp, dp, dp]),
+    "ocs_compute_x_lam_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
+    "ocs_fb_sweep": (C.c_int, [vp, vp, C.c_int, dp, vp, dp, dp, dp, dp, dp, dp, ip, dp]),
+    "ocs_fb_sweep_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ocs_to_batch_minor_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "ocs_to_traj_major_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
 }
@@ -83,6 +88,12 @@ for _name, (_res, _args) in _SIG.items():
     _fn = getattr(lib, _name)
     _fn.restype = _res
     _fn.argtypes = _args
+
+
+class FbsOptions(C.Structure):
+    """struct ocs_fbs_options (include/ocs.h)."""
+    _fields_ = [("uRelTol", C.c_double), ("uAbsTol", C.c_double), ("nSWEEPS", C.c_int),
+                ("nERROR_PTS", C.c_int), ("nINTERP_PTS", C.c_int)]
 
 
 def declared_symbols():

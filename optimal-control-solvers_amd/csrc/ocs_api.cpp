@@ -216,6 +216,7 @@ int ocs_rk4inf_create(ocs_integrator* out, const double* tspan, int npts, const 
 int ocs_integrator_destroy(ocs_integrator g) {
   if (!g) return OCS_OK;
   if (g->leg2) ocs_integrator_destroy(g->leg2);
+  if (g->fbs) ocs_fbs_state_free(g->fbs);
   g->d_ustar.release();
   g->d_lam2.release();
   if (g->stream) (void)hipStreamDestroy(g->stream);

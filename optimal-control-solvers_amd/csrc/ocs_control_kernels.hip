@@ -63,6 +63,18 @@ __global__ void k_scatter_rows(int nrows, int batch, const int* __restrict__ idx
   dst[(size_t)idx[r] * batch + b] = src[(size_t)r * batch + b];
 }
 
+// out[j][c][b] = val[c]  (u0 = ControlBounds(:,1)*ones(1,length(t)), fb_sweep.m:23)
+__global__ void k_fill_rows(int ncols, int nC, int batch, const double* __restrict__ val, double* __restrict__ out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  if (b >= batch || j >= ncols) return;
+  for (int c = 0; c < nC; ++c) out[((size_t)j * nC + c) * batch + b] = val[c];
+}
+int launch_fill_rows(int ncols, int nC, int batch, const double* val, double* out, hipStream_t s) {
+  k_fill_rows<<<dim3((batch + 255) / 256, ncols), dim3(256), 0, s>>>(ncols, nC, batch, val, out);
+  return hip_rc2(hipGetLastError());
+}
+
 int launch_basis_expand(int nT, int nC, int batch, const int* colptr, const int* row, const double* val,
                         const double* v, double* u, hipStream_t s) {
   k_basis_expand<<<dim3((batch + 255) / 256, nT), dim3(256), 0, s>>>(nT, nC, batch, colptr, row, val, v, u);

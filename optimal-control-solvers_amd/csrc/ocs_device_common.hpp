@@ -1,0 +1,73 @@
+// ocs_device_common.hpp -- device helpers shared by the kernel translation units.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace ocs {
+
+#define OCS_INLINE __attribute__((always_inline))
+
+// Wave-uniform read-only tables (step sizes, time coefficients, shared parameters) are read
+// through the constant address space so the backend emits scalar (s_load) instead of
+// per-lane vector loads: `__restrict__` on struct members does not reach alias analysis.
+typedef const double __attribute__((address_space(4))) * uniform_ptr;
+__device__ static inline uniform_ptr as_uniform(const double* p) { return (uniform_ptr)p; }
+#define PSU(p) as_uniform(p)
+
+// ---------------------------------------------------------------------------------------
+// per-step record table
+// ---------------------------------------------------------------------------------------
+// Everything wave-uniform that step i needs sits in one 64-byte-aligned record so that a
+// single s_load_dwordx16 (NTC = 1) fetches it, issued one step ahead of its use:
+//   REC[i] = { h, h/2, h/6, h/3, tc(t_2i)[NTC], tc(t_2i+1)[NTC], tc(t_2i+2)[NTC], pad }
+__host__ __device__ constexpr int rec_stride(int ntc) { return ((4 + 3 * ntc + 7) / 8) * 8; }
+
+template <int NTC>
+struct StepRec {
+  double h, hh, h6, h3;
+  double tcA[NTC], tcM[NTC], tcB[NTC];
+};
+// Records are read through the VECTOR memory path (every lane loads the same address): vector
+// loads return in order, so a ring of RD records can be kept in flight with counted vmcnt
+// waits.  Scalar loads return out of order, every wait is lgkmcnt(0), and the newest
+// prefetch would always be waited for together with the record that is needed (measured:
+// +40 % time per step).
+template <int NTC>
+__device__ static inline StepRec<NTC> load_rec(const double* REC, int i) {
+  const double* q = REC + (size_t)i * rec_stride(NTC);
+  StepRec<NTC> r;
+  r.h = q[0];
+  r.hh = q[1];
+  r.h6 = q[2];
+  r.h3 = q[3];
+#pragma unroll
+  for (int k = 0; k < NTC; ++k) {
+    r.tcA[k] = q[4 + k];
+    r.tcM[k] = q[4 + NTC + k];
+    r.tcB[k] = q[4 + 2 * NTC + k];
+  }
+  return r;
+}
+
+// The record table is written by another kernel and is cold in this XCD's L2: a scalar load
+// that misses to the Infinity Cache / HBM costs more than a whole RK4 step.  Every wave
+// therefore sweeps the table once with wide vector loads (1 KiB per instruction) before the
+// recursion starts, so the per-step scalar loads that follow are L2 hits.
+__device__ static inline double warm_table(const double* tab, size_t ndoubles) {
+  typedef double double2v __attribute__((ext_vector_type(2)));
+  const double2v* q = reinterpret_cast<const double2v*>(tab);
+  const size_t n2 = ndoubles / 2;
+  double acc = 0.0;
+  size_t k = threadIdx.x & 63;
+  for (; k + 15 * 64 < n2; k += 16 * 64) {
+    double2v v[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = q[k + (size_t)j * 64];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc += v[j].x + v[j].y;
+  }
+  for (; k < n2; k += 64) acc += q[k].x + q[k].y;
+  return acc;  // the caller keeps it alive behind a never-taken branch
+}
+
+
+}  // namespace ocs

@@ -1,0 +1,360 @@
+// ocs_fbs.cpp -- forward-backward sweep driver (functions/fb_sweep.m, compute_x_lam.m,
+// compute_x_lam_J.m) on the integrator grid, batch-aware: every instance carries its own
+// convergence state, the whole batch advances sweep by sweep until no instance is active.
+#include "ocs_handles.hpp"
+
+#include <algorithm>
+
+using namespace ocs;
+
+struct ocs_fbs_state {
+  // pchip node tables
+  DevBuf TN, HN, W1, W2, TM;
+  bool tables = false;
+  // query-point tables (error points / interp points), rebuilt when the options change
+  int nerr = 0, nint = 0;
+  DevBuf KE, SE, TE, TUE, KI, SI, TI, TUI;
+  unsigned long long tu_version = 0;
+  const ocs_problem_s* tu_prob = nullptr;
+  // work arrays
+  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage;
+};
+
+void ocs_fbs_state_free(ocs_fbs_state* s) {
+  if (!s) return;
+  DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
+                    &s->TI, &s->TUI, &s->xaug, &s->xmid, &s->lam, &s->lmid, &s->ugrid, &s->uerr, &s->uint_, &s->J,
+                    &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage};
+  for (DevBuf* b : bufs) b->release();
+  delete s;
+}
+
+static void matlab_linspace(double a, double b, int n, std::vector<double>& out) {
+  out.resize(n);
+  if (n == 1) {
+    out[0] = b;
+    return;
+  }
+  const int n1 = n - 1;
+  for (int k = 0; k <= n1; ++k) out[k] = a + ((double)k * (b - a)) / (double)n1;
+  out[0] = a;
+  out[n1] = b;
+}
+
+static int upload(DevBuf& d, const void* src, size_t bytes) {
+  OCS_TRY(d.ensure(bytes ? bytes : 8));
+  if (bytes) HIP_TRY(hipMemcpy(d.p, src, bytes, hipMemcpyHostToDevice));
+  return OCS_OK;
+}
+
+static int ensure_tables(ocs_integrator_s* g) {
+  if (!g->fbs) g->fbs = new ocs_fbs_state();
+  ocs_fbs_state* f = g->fbs;
+  if (f->tables) return OCS_OK;
+  const int N = g->N, n = N + 1;
+  std::vector<double> tn(n), tm(N), w1(n, 0.0), w2(n, 0.0);
+  for (int i = 0; i < n; ++i) tn[i] = g->t[2 * (size_t)i];
+  for (int i = 0; i < N; ++i) tm[i] = g->t[2 * (size_t)i + 1];
+  const std::vector<double>& h = g->h;
+  for (int k = 1; k + 1 < n; ++k) {  // pchip interior weights (MATLAB pchipslopes)
+    const double hs = h[k - 1] + h[k];
+    w1[k] = (h[k - 1] + hs) / (3 * hs);
+    w2[k] = (hs + h[k]) / (3 * hs);
+  }
+  OCS_TRY(upload(f->TN, tn.data(), sizeof(double) * n));
+  OCS_TRY(upload(f->HN, h.data(), sizeof(double) * N));
+  OCS_TRY(upload(f->W1, w1.data(), sizeof(double) * n));
+  OCS_TRY(upload(f->W2, w2.data(), sizeof(double) * n));
+  OCS_TRY(upload(f->TM, tm.data(), sizeof(double) * N));
+  f->tables = true;
+  return OCS_OK;
+}
+
+static FbsTables tabs(const ocs_integrator_s* g) {
+  const ocs_fbs_state* f = g->fbs;
+  return FbsTables{g->N + 1, f->TN.d(), f->HN.d(), f->W1.d(), f->W2.d(), f->TM.d()};
+}
+
+// interval index and local coordinate of query points linspace(T0, TF, nq)
+static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBuf& T) {
+  const int n = g->N + 1;
+  std::vector<double> q, tn(n), s(nq);
+  std::vector<int> k(nq);
+  for (int i = 0; i < n; ++i) tn[i] = g->t[2 * (size_t)i];
+  matlab_linspace(tn[0], tn[n - 1], nq, q);  // fb_sweep.m:69-70
+  for (int j = 0; j < nq; ++j) {
+    int lo = 0, hi = n - 1;
+    if (q[j] <= tn[0])
+      lo = 0;
+    else if (q[j] >= tn[n - 1])
+      lo = n - 2;
+    else {
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        if (tn[mid] <= q[j])
+          lo = mid;
+        else
+          hi = mid;
+      }
+    }
+    k[j] = lo;
+    s[j] = q[j] - tn[lo];
+  }
+  OCS_TRY(upload(K, k.data(), sizeof(int) * nq));
+  OCS_TRY(upload(S, s.data(), sizeof(double) * nq));
+  OCS_TRY(upload(T, q.data(), sizeof(double) * nq));
+  return OCS_OK;
+}
+
+extern "C" {
+
+int ocs_fbs_default_options(ocs_fbs_options* o) {
+  if (!o) return fail(OCS_ERR_INVALID, "null argument");
+  o->uRelTol = 1e-7;      // fb_sweep.m:16
+  o->uAbsTol = 1e-7;      // :17
+  o->nSWEEPS = 50;        // :20
+  o->nERROR_PTS = 1001;   // :21
+  o->nINTERP_PTS = 1001;  // :22
+  return OCS_OK;
+}
+
+// [x, lam] = compute_x_lam(prob, x0, tspan, u, ...) / [x, lam, J] = compute_x_lam_J(...) on the grid.
+// device: x0 [nS][B], ugrid [2N+1][nC][B] -> xaug [N+1][nAug][B] (states + running objective, the
+// augmented system of compute_x_lam_J.m:6-15), lam [N+1][nS][B], J [B] (may be NULL).
+int ocs_compute_x_lam_dev(ocs_integrator g, ocs_problem p, int batch, const double* x0, const double* ugrid,
+                          double* xaug, double* lam, double* J, void* stream) {
+  if (!g || !p || !x0 || !ugrid || !xaug || !lam || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
+  if (g->kind != 0) return fail(OCS_ERR_UNSUPPORTED, "compute_x_lam needs an RK4Integrator grid");
+  hipStream_t s = (hipStream_t)stream;
+  OCS_TRY(bind_problem(g, p, batch, s));
+  OCS_TRY(ensure_tables(g));
+  ocs_fbs_state* f = g->fbs;
+  const int N = g->N, nS = p->nS, nAug = nS + 1;
+  const size_t B = (size_t)batch;
+  OCS_TRY(f->xmid.ensure(sizeof(double) * (size_t)N * nS * B));
+  double* Jd = J;
+  if (!Jd) {
+    OCS_TRY(f->J.ensure(sizeof(double) * B));
+    Jd = f->J.d();
+  }
+  LAUNCH_TRY(launch_forward(describe(p), describe(g), batch, x0, ugrid, xaug, Jd, FwdOpts(), s));
+  LAUNCH_TRY(launch_pchip_mid(tabs(g), nS, nAug, batch, xaug, f->xmid.d(), s));
+  LAUNCH_TRY(launch_costate(describe(p), describe(g), batch, xaug, nAug, f->xmid.d(), ugrid, nullptr, 0, lam, s));
+  return OCS_OK;
+}
+
+// soln = fb_sweep(prob, x0, tspan, options)   functions/fb_sweep.m:1-126 on the grid of `g`.
+// device: x0 [nS][B]; u0grid [2N+1][nC][B] / u0err [nERR][nC][B] or NULL (lower bound, :23);
+// outputs xaug [N+1][nAug][B], lam [N+1][nS][B], uInterp [nINTERP][nC][B], J [B],
+// sweeps int[B] (sweep index at which the instance converged, 0 = never: soln stays empty, :77),
+// maxChange [nSWEEPS][B] or NULL (the per-sweep value printed at :109; NaN where not run).
+// Returns OCS_NUM_NOT_CONVERGED if any instance used all nSWEEPS sweeps.
+int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x0, const ocs_fbs_options* opt,
+                     const double* u0grid, const double* u0err, double* xaug, double* lam, double* uInterp,
+                     double* J, int* sweeps, double* maxChange, void* stream) {
+  if (!g || !p || !x0 || !opt || !xaug || !lam || !uInterp || !J || !sweeps || batch < 1)
+    return fail(OCS_ERR_INVALID, "bad argument");
+  if (g->kind != 0) return fail(OCS_ERR_UNSUPPORTED, "fb_sweep needs an RK4Integrator grid");
+  if (opt->nSWEEPS < 1 || opt->nERROR_PTS < 2 || opt->nINTERP_PTS < 2) return fail(OCS_ERR_INVALID, "bad options");
+  if ((u0grid == nullptr) != (u0err == nullptr)) return fail(OCS_ERR_INVALID, "give both u0grid and u0err or neither");
+  hipStream_t s = (hipStream_t)stream;
+  OCS_TRY(bind_problem(g, p, batch, s));
+  OCS_TRY(ensure_tables(g));
+  ocs_fbs_state* f = g->fbs;
+  const int N = g->N, nS = p->nS, nC = p->nC, nAug = nS + 1, nT = 2 * N + 1;
+  const int nE = opt->nERROR_PTS, nI = opt->nINTERP_PTS;
+  const size_t B = (size_t)batch;
+  const int ntu = std::max(1, functor_ntu(p->functor, p->nS));
+  bool newpts = false;
+  if (f->nerr != nE) {
+    OCS_TRY(build_points(g, nE, f->KE, f->SE, f->TE));
+    f->nerr = nE;
+    newpts = true;
+  }
+  if (f->nint != nI) {
+    OCS_TRY(build_points(g, nI, f->KI, f->SI, f->TI));
+    f->nint = nI;
+    newpts = true;
+  }
+  if (newpts || f->tu_prob != p || f->tu_version != p->version) {
+    OCS_TRY(f->TUE.ensure(sizeof(double) * (size_t)nE * ntu));
+    OCS_TRY(f->TUI.ensure(sizeof(double) * (size_t)nI * ntu));
+    LAUNCH_TRY(launch_tu_at(describe(p), nE, f->TE.d(), f->TUE.d(), s));
+    LAUNCH_TRY(launch_tu_at(describe(p), nI, f->TI.d(), f->TUI.d(), s));
+    f->tu_prob = p;
+    f->tu_version = p->version;
+  }
+  const size_t ugridN = (size_t)nT * nC * B, uerrN = (size_t)nE * nC * B;
+  OCS_TRY(f->xmid.ensure(sizeof(double) * (size_t)N * nS * B));
+  OCS_TRY(f->lmid.ensure(sizeof(double) * (size_t)N * nS * B));
+  OCS_TRY(f->ugrid.ensure(sizeof(double) * 2 * ugridN));
+  OCS_TRY(f->uerr.ensure(sizeof(double) * 2 * uerrN));
+  OCS_TRY(f->usel.ensure(sizeof(int) * B));
+  OCS_TRY(f->nactive.ensure(sizeof(int)));
+  double* mc = maxChange;
+  if (!mc) {
+    OCS_TRY(f->maxchange.ensure(sizeof(double) * (size_t)opt->nSWEEPS * B));
+    mc = f->maxchange.d();
+  }
+  int* status = sweeps;
+  HIP_TRY(hipMemsetAsync(f->usel.p, 0, sizeof(int) * B, s));
+  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int) * B, s));
+  HIP_TRY(hipMemsetAsync(mc, 0xFF, sizeof(double) * (size_t)opt->nSWEEPS * B, s));  // all-ones = NaN
+  if (u0grid) {  // u = u0  :76
+    HIP_TRY(hipMemcpyAsync(f->ugrid.p, u0grid, sizeof(double) * ugridN, hipMemcpyDeviceToDevice, s));
+    HIP_TRY(hipMemcpyAsync(f->uerr.p, u0err, sizeof(double) * uerrN, hipMemcpyDeviceToDevice, s));
+  } else {       // u0 = ControlBounds(:,1)*ones(1,length(t))  :23
+    LAUNCH_TRY(launch_fill_rows(nT, nC, batch, p->d_lb.d(), f->ugrid.d(), s));
+    LAUNCH_TRY(launch_fill_rows(nE, nC, batch, p->d_lb.d(), f->uerr.d(), s));
+  }
+  const ProblemDesc pd = describe(p);
+  const GridDesc gd = describe(g);
+  const FbsTables tb = tabs(g);
+  const int* usel = (const int*)f->usel.p;
+  FwdOpts fo;
+  fo.usel = usel;
+  fo.udelta = (long long)ugridN;
+  int nactive = batch;
+  for (int sweep = 1; sweep <= opt->nSWEEPS && nactive > 0; ++sweep) {  // :79
+    // uNew = sweep(u): compute_x_lam (:95) then uNew = ControlChar(t, x(t), lam(t)) (:96)
+    LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
+    LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
+    LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), usel, (long long)ugridN, lam, s));
+    LAUNCH_TRY(launch_pchip_mid(tb, nS, nS, batch, lam, f->lmid.d(), s));
+    LAUNCH_TRY(launch_control_grid(pd, gd, batch, xaug, nAug, f->xmid.d(), lam, f->lmid.d(), f->ugrid.d(), usel,
+                                   (long long)ugridN, s));
+    LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
+                                  f->uerr.d(), usel, (long long)uerrN, s));
+    // check_convergence(uNew, u)  :81, :99-115
+    HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));
+    LAUNCH_TRY(launch_fbs_advance(batch, nE, nC, sweep, opt->uRelTol, opt->uAbsTol, f->uerr.d(), (long long)uerrN,
+                                  (int*)f->usel.p, status, mc, (int*)f->nactive.p, s));
+    HIP_TRY(hipMemcpyAsync(&nactive, f->nactive.p, sizeof(int), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+  }
+  // final_sweep(u) (:82, :117-125): x, lam, J of a converged instance already belong to its OLD control
+  // (a frozen instance is re-integrated with the same u each later sweep, bit for bit); what is left is
+  // uOpt = ControlChar(interpPts, xOpt(interpPts), lamOpt(interpPts))  :123
+  LAUNCH_TRY(launch_control_pts(pd, tb, nI, (const int*)f->KI.p, f->SI.d(), f->TUI.d(), batch, xaug, nAug, lam,
+                                uInterp, nullptr, 0, s));
+  return nactive > 0 ? OCS_NUM_NOT_CONVERGED : OCS_OK;
+}
+
+// host: x0 nS x batch; u0grid nC x (2N+1) x batch, u0err nC x nERR x batch (or both NULL);
+// x nS x (N+1) x batch, lam nS x (N+1) x batch, uInterp nC x nINTERP x batch, J batch, sweeps batch,
+// maxChange nSWEEPS x batch (or NULL).
+int ocs_fb_sweep(ocs_integrator g, ocs_problem p, int batch, const double* x0, const ocs_fbs_options* opt,
+                 const double* u0grid, const double* u0err, double* x, double* lam, double* uInterp, double* J,
+                 int* sweeps, double* maxChange) {
+  if (!g || !p || !x0 || !opt || !x || !lam || !uInterp || !J || !sweeps || batch < 1)
+    return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(upload_grid(g));
+  OCS_TRY(ensure_tables(g));
+  ocs_fbs_state* f = g->fbs;
+  const int N = g->N, nS = p->nS, nC = p->nC, nAug = nS + 1, nT = 2 * N + 1;
+  const int nE = opt->nERROR_PTS, nI = opt->nINTERP_PTS;
+  const size_t B = (size_t)batch;
+  hipStream_t s = g->stream;
+  auto in = [&](const double* host, DevBuf& dst, int per) -> int {
+    const size_t bytes = sizeof(double) * (size_t)per * B;
+    HIP_TRY(hipStreamSynchronize(s));
+    OCS_TRY(f->stage.ensure(bytes));
+    OCS_TRY(dst.ensure(bytes));
+    HIP_TRY(hipMemcpyAsync(f->stage.p, host, bytes, hipMemcpyHostToDevice, s));
+    LAUNCH_TRY(launch_to_batch_minor(f->stage.d(), dst.d(), per, batch, s));
+    return OCS_OK;
+  };
+  auto out = [&](const double* src, double* host, int per) -> int {
+    const size_t bytes = sizeof(double) * (size_t)per * B;
+    OCS_TRY(f->stage.ensure(bytes));
+    LAUNCH_TRY(launch_to_traj_major(src, f->stage.d(), per, batch, s));
+    HIP_TRY(hipMemcpyAsync(host, f->stage.p, bytes, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    return OCS_OK;
+  };
+  OCS_TRY(in(x0, f->x0, nS));
+  DevBuf dug, due;
+  int rc = OCS_OK;
+  auto body = [&]() -> int {
+    if (u0grid) {
+      OCS_TRY(in(u0grid, dug, nC * nT));
+      OCS_TRY(in(u0err, due, nC * nE));
+    }
+    OCS_TRY(f->xaug.ensure(sizeof(double) * (size_t)(N + 1) * nAug * B));
+    OCS_TRY(f->lam.ensure(sizeof(double) * (size_t)(N + 1) * nS * B));
+    OCS_TRY(f->uint_.ensure(sizeof(double) * (size_t)nI * nC * B));
+    OCS_TRY(f->J.ensure(sizeof(double) * B));
+    OCS_TRY(f->status.ensure(sizeof(int) * B));
+    OCS_TRY(f->maxchange.ensure(sizeof(double) * (size_t)opt->nSWEEPS * B));
+    const int st = ocs_fb_sweep_dev(g, p, batch, f->x0.d(), opt, u0grid ? dug.d() : nullptr, u0grid ? due.d() : nullptr,
+                                    f->xaug.d(), f->lam.d(), f->uint_.d(), f->J.d(), (int*)f->status.p,
+                                    f->maxchange.d(), s);
+    if (st < 0) return st;
+    // drop the running-objective row: soln.x has the nS state rows
+    std::vector<double> tmp((size_t)(N + 1) * nAug * B);
+    OCS_TRY(out(f->xaug.d(), tmp.data(), (N + 1) * nAug));
+    for (size_t b = 0; b < B; ++b)
+      for (int i = 0; i <= N; ++i)
+        for (int k = 0; k < nS; ++k)
+          x[(b * (N + 1) + i) * nS + k] = tmp[(b * (N + 1) + i) * nAug + k];
+    OCS_TRY(out(f->lam.d(), lam, (N + 1) * nS));
+    OCS_TRY(out(f->uint_.d(), uInterp, nI * nC));
+    HIP_TRY(hipMemcpy(J, f->J.p, sizeof(double) * B, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(sweeps, f->status.p, sizeof(int) * B, hipMemcpyDeviceToHost));
+    if (maxChange) {  // [nSWEEPS][B] on the device -> nSWEEPS x batch column-major on the host
+      OCS_TRY(out(f->maxchange.d(), maxChange, opt->nSWEEPS));
+    }
+    return st;
+  };
+  rc = body();
+  dug.release();
+  due.release();
+  return rc;
+}
+
+// host compute_x_lam(_J): x0 nS x batch, ugrid nC x (2N+1) x batch -> x nS x (N+1) x batch, lam same, J (or NULL)
+int ocs_compute_x_lam(ocs_integrator g, ocs_problem p, int batch, const double* x0, const double* ugrid, double* x,
+                      double* lam, double* J) {
+  if (!g || !p || !x0 || !ugrid || !x || !lam || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(upload_grid(g));
+  OCS_TRY(ensure_tables(g));
+  ocs_fbs_state* f = g->fbs;
+  const int N = g->N, nS = p->nS, nC = p->nC, nAug = nS + 1, nT = 2 * N + 1;
+  const size_t B = (size_t)batch;
+  hipStream_t s = g->stream;
+  DevBuf dug;
+  auto body = [&]() -> int {
+    const size_t bx = sizeof(double) * (size_t)nS * B, bu = sizeof(double) * (size_t)nC * nT * B;
+    OCS_TRY(f->stage.ensure(std::max(bx, bu)));
+    OCS_TRY(f->x0.ensure(bx));
+    OCS_TRY(dug.ensure(bu));
+    HIP_TRY(hipMemcpy(f->stage.p, x0, bx, hipMemcpyHostToDevice));
+    LAUNCH_TRY(launch_to_batch_minor(f->stage.d(), f->x0.d(), nS, batch, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    HIP_TRY(hipMemcpy(f->stage.p, ugrid, bu, hipMemcpyHostToDevice));
+    LAUNCH_TRY(launch_to_batch_minor(f->stage.d(), dug.d(), nC * nT, batch, s));
+    OCS_TRY(f->xaug.ensure(sizeof(double) * (size_t)(N + 1) * nAug * B));
+    OCS_TRY(f->lam.ensure(sizeof(double) * (size_t)(N + 1) * nS * B));
+    OCS_TRY(f->J.ensure(sizeof(double) * B));
+    OCS_TRY(ocs_compute_x_lam_dev(g, p, batch, f->x0.d(), dug.d(), f->xaug.d(), f->lam.d(), f->J.d(), s));
+    std::vector<double> tmp((size_t)(N + 1) * nAug * B);
+    OCS_TRY(f->stage.ensure(sizeof(double) * tmp.size()));
+    LAUNCH_TRY(launch_to_traj_major(f->xaug.d(), f->stage.d(), (N + 1) * nAug, batch, s));
+    HIP_TRY(hipMemcpyAsync(tmp.data(), f->stage.p, sizeof(double) * tmp.size(), hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    for (size_t b = 0; b < B; ++b)
+      for (int i = 0; i <= N; ++i)
+        for (int k = 0; k < nS; ++k)
+          x[(b * (N + 1) + i) * nS + k] = tmp[(b * (N + 1) + i) * nAug + k];
+    LAUNCH_TRY(launch_to_traj_major(f->lam.d(), f->stage.d(), (N + 1) * nS, batch, s));
+    HIP_TRY(hipMemcpyAsync(lam, f->stage.p, sizeof(double) * (size_t)(N + 1) * nS * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    if (J) HIP_TRY(hipMemcpy(J, f->J.p, sizeof(double) * B, hipMemcpyDeviceToHost));
+    return OCS_OK;
+  };
+  const int rc = body();
+  dug.release();
+  return rc;
+}
+
+}  // extern "C"

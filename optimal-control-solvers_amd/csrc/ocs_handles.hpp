@@ -110,8 +110,12 @@ struct ocs_problem_s {
   bool uploaded = false;
 };
 
+struct ocs_fbs_state;  // forward-backward-sweep workspace (ocs_fbs.cpp)
+void ocs_fbs_state_free(ocs_fbs_state* s);
+
 struct ocs_integrator_s {
   using DevBuf = ocs::DevBuf;
+  ocs_fbs_state* fbs = nullptr;
   int kind = 0;  // 0 RK4Integrator, 1 RK4InfiniteIntegrator (then `leg2` and `ustar` are set)
   ocs_integrator_s* leg2 = nullptr;   // integrator2 of RK4InfiniteIntegrator.m:13-14
   std::vector<double> ustar;          // uStar (nC)

@@ -62,8 +62,31 @@ int launch_basis_expand(int nT, int nC, int batch, const int* colptr, const int*
                         const double* v, double* u, hipStream_t s);
 int launch_basis_contract(int nBasis, int nC, int batch, const int* rowptr, const int* col, const double* val,
                           const double* dJdu, double* dJdv, hipStream_t s);
+int launch_fill_rows(int ncols, int nC, int batch, const double* val, double* out, hipStream_t s);
 int launch_gather_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
 int launch_scatter_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
+
+// forward-backward sweep (ocs_fbs_kernels.hip)
+struct FbsTables {   // pchip node tables of an integrator grid, device pointers
+  int n;             // number of nodes N+1
+  const double* TN;  // [n] node times
+  const double* HN;  // [n-1] spacings
+  const double* W1;  // [n] interior slope weights (entries 1..n-2 used)
+  const double* W2;
+  const double* TM;  // [n-1] interval midpoints
+};
+int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s);
+int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
+                   const double* u, const int* usel, long long udelta, double* lam, hipStream_t s);
+int launch_control_grid(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx,
+                        const double* xmid, const double* lam, const double* lmid, double* u, const int* usel,
+                        long long udelta, hipStream_t s);
+int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
+                       const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
+                       const int* usel, long long odelta, hipStream_t s);
+int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
+int launch_fbs_advance(int batch, int nerr, int nC, int sweep, double relTol, double absTol, const double* uerr,
+                       long long edelta, int* usel, int* status, double* maxChange, int* nactive, hipStream_t s);
 
 // registry queries (host)
 bool functor_supported(Functor f, int nS, int nC);

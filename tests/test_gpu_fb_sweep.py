@@ -1,0 +1,130 @@
+"""GPU parity of the grid forward-backward sweep (A9/A10) against the CPU oracle's restatement of
+the same scheme (fb_sweep.m with odevr7 -> grid RK4 + pchip coupling).  north_star tolerance for
+fb_sweep output: 1e-10 relative; the sweep is a contraction here, so GPU/CPU last-bit differences
+do not grow across sweeps and the passes themselves agree to ~1e-13."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+P = {"c": 1.5, "m": 3.0, "r": 0.05}
+BOUNDS = [[0.0, 1.0]]
+RTOL = 1e-10
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def ocs():
+    import torch
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def test_compute_x_lam_matches_oracle(ocs, oracle):
+    rng = np.random.default_rng(2)
+    for m, N, tspan in (([3.0], 200, oracle.linspace(0, 10, 201)),
+                        ([3.0, 2.5], 60, np.sort(np.concatenate([[0.0, 6.0], rng.uniform(0, 6, 59)]))),
+                        ([3.0], 1, np.array([0.0, 0.1])), ([3.0], 2, np.array([0.0, 0.1, 0.25]))):
+        nS, N = len(m), tspan.size - 1
+        pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+        batch = 67
+        u = rng.uniform(0.05, 0.45, (1, 2 * N + 1, batch))
+        x0 = rng.uniform(0.9, 2.2, (nS, batch))
+        x, lam, J = ocs.compute_x_lam_J(pg, x0, tspan, u)
+        go = oracle.RK4Integrator(tspan)
+        for b in (0, 1, 65, 66):
+            xo, lo, Jo = oracle.compute_x_lam(go, po, x0[:, b], u[:, :, b], want_J=True)
+            assert relerr(x[:, :, b], xo) < 1e-12 and relerr(lam[:, :, b], lo) < 1e-12
+            assert abs(J[b] - Jo) < 1e-12 * max(1.0, abs(Jo))
+        assert np.all(lam[:, -1, :] == 0.0)  # lam(TF) = 0*x0  compute_x_lam.m:4
+
+
+def test_fb_sweep_single_instance_like_the_reference(ocs, oracle):
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    tspan = oracle.linspace(0, 10, 1001)
+    soln = ocs.fb_sweep(prob, [1.0], tspan)
+    assert set(soln) == {"x", "lam", "u", "J"}
+    ref = oracle.fb_sweep(oracle.TestOCProblem(P, BOUNDS), [1.0], tspan)
+    assert ref["_sweeps"] > 0
+    tq = ref["_interpPts"]
+    assert abs(soln["J"] - ref["J"]) < RTOL * abs(ref["J"])
+    assert relerr(soln["u"](tq), ref["u"]) < RTOL
+    assert relerr(soln["x"](tspan), ref["x"]) < RTOL and relerr(soln["lam"](tspan), ref["lam"]) < RTOL
+    # turnpike: the optimal harvest sits at the analytic equilibrium in mid-horizon (SURVEY KAT 1)
+    assert abs(soln["u"](np.array([5.0]))[0, 0] - 0.72336878009798256) < 1e-3
+    # non-convergence -> empty struct (fb_sweep.m:77)
+    assert ocs.fb_sweep(prob, [1.0], tspan, {"nSWEEPS": 2}) == {}
+
+
+def test_fb_sweep_batch_bl3_style(ocs, oracle):
+    """SURVEY BL-3: instances differ in x0 ~ U(0.5,2.5) and c ~ U(1,2); per-instance sweep counts,
+    maxChange histories and solutions must match the oracle run instance by instance."""
+    rng = np.random.default_rng(20260402)
+    batch, N = 70, 400
+    tspan = oracle.linspace(0, 10, N + 1)
+    x0 = rng.uniform(0.5, 2.5, (1, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    opts = {"nERROR_PTS": 401, "nINTERP_PTS": 201}
+    r = ocs.fb_sweep_batch(prob, x0, tspan, opts)
+    assert r["status"] == 0 and r["sweeps"].min() >= 3 and r["sweeps"].max() <= 20
+    assert len(set(r["sweeps"].tolist())) > 1  # instances really stop at different sweeps
+    for b in (0, 1, 13, 63, 64, 69):
+        ref = oracle.fb_sweep(oracle.TestOCProblem({"c": cs[b], "m": P["m"], "r": P["r"]}, BOUNDS), x0[:, b], tspan, opts)
+        k = ref["_sweeps"]
+        assert r["sweeps"][b] == k
+        mc = r["maxChange"][:, b]
+        assert relerr(mc[:k], ref["_maxChange"][:k]) < 1e-6 and np.all(np.isnan(mc[k:]))
+        assert abs(r["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
+        assert relerr(r["x"][:, :, b], ref["x"]) < RTOL and relerr(r["lam"][:, :, b], ref["lam"]) < RTOL
+        assert relerr(r["u"][:, :, b], ref["u"]) < RTOL
+
+
+def test_fb_sweep_options_u0_and_offgrid_error_points(ocs, oracle):
+    # numeric u0 (evenly spaced samples -> pchip, fb_sweep.m:61-66) and error points that are NOT grid nodes
+    tspan = oracle.linspace(0, 8, 161)
+    u0 = np.array([[0.2, 0.6, 0.9, 0.4, 0.1]])
+    opts = {"u0": u0, "nERROR_PTS": 333, "nINTERP_PTS": 77, "uRelTol": 1e-6, "uAbsTol": 1e-6}
+    prob = ocs.LogisticProblem([3.0, 2.5], P["c"], P["r"], BOUNDS)
+    r = ocs.fb_sweep_batch(prob, np.array([[1.0], [1.5]]), tspan, opts)
+    ref = oracle.fb_sweep(oracle.LogisticProblem([3.0, 2.5], P["c"], P["r"], BOUNDS), [1.0, 1.5], tspan, opts)
+    assert r["sweeps"][0] == ref["_sweeps"] > 0
+    assert abs(r["J"][0] - ref["J"]) < RTOL * abs(ref["J"])
+    assert relerr(r["u"][:, :, 0], ref["u"]) < RTOL and relerr(r["lam"][:, :, 0], ref["lam"]) < RTOL
+    # callable u0
+    r2 = ocs.fb_sweep_batch(prob, np.array([[1.0], [1.5]]), tspan, {"u0": lambda t: 0.3 + 0.0 * np.atleast_2d(t)})
+    ref2 = oracle.fb_sweep(oracle.LogisticProblem([3.0, 2.5], P["c"], P["r"], BOUNDS), [1.0, 1.5], tspan,
+                           {"u0": lambda t: 0.3 + 0.0 * np.atleast_2d(t)})
+    assert r2["sweeps"][0] == ref2["_sweeps"] and abs(r2["J"][0] - ref2["J"]) < RTOL * abs(ref2["J"])
+
+
+def test_fb_sweep_full_size_properties(ocs, oracle):
+    """BASELINE config 3 shape on device buffers (batch reduced to 4096 for test time): every instance
+    converges, solutions satisfy the optimality system, spot checks against the oracle."""
+    import torch
+    rng = np.random.default_rng(20260402)
+    batch, N = 4096, 1000
+    tspan = oracle.linspace(0, 10, N + 1)
+    x0 = rng.uniform(0.5, 2.5, (1, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    integ = ocs.RK4Integrator(tspan)
+    r = ocs.fb_sweep_dev(prob, integ, torch.tensor(x0, device="cuda:0"))
+    torch.cuda.synchronize()
+    sw = r["sweeps"].cpu().numpy()
+    assert r["status"] == 0 and sw.min() > 0
+    u = r["u"].cpu().numpy()[:, 0, :]            # [nINTERP][B]
+    lam = r["lam"].cpu().numpy()[:, 0, :]        # [N+1][B]
+    assert np.all(u >= 0.0) and np.all(u <= 1.0) and np.all(lam[-1] == 0.0)
+    # ControlChar identity at the nodes: u = clamp(lam e^{rt} / (2c), 0, 1)   (interpPts == nodes here)
+    expect = np.clip(lam * np.exp(P["r"] * tspan)[:, None] / (2 * cs[None, :]), 0.0, 1.0)
+    assert np.max(np.abs(u - expect)) < 1e-12
+    for b in (0, 4095):
+        ref = oracle.fb_sweep(oracle.TestOCProblem({"c": cs[b], "m": P["m"], "r": P["r"]}, BOUNDS), x0[:, b], tspan)
+        assert sw[b] == ref["_sweeps"] and abs(r["J"][b].item() - ref["J"]) < RTOL * abs(ref["J"])
