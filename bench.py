@@ -81,6 +81,34 @@ def cpu_baseline(tspan, x0, u, target_seconds=12.0):
                       f"x/J/lam/dJdu written) in {dt:.1f} s, oracle/ocs_oracle.c with OpenMP over the batch"}, out
 
 
+def fb_sweep_metric(ocs, dev, batch=16384, reps=3):
+    """Second half of BASELINE.json's metric: fb_sweep iters/sec on configs[2] (SURVEY BL-3):
+    TestOCProblem through the A9 adapter, T=10, N=1000 forward + 1000 backward, batch=16384 instances with
+    x0 ~ U(0.5,2.5), c ~ U(1,2) (seed 20260402), u0 = lower bound, default tolerances, <= 50 sweeps.
+    One iter = forward + costate + control update + convergence reduction for one instance; converged
+    instances stop counting (the whole batch still runs until the last one is done)."""
+    rng = np.random.default_rng(20260402)
+    tspan = np.linspace(0.0, T_END, NSTEPS + 1)
+    x0 = torch.tensor(rng.uniform(0.5, 2.5, (1, batch)), device=dev)
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
+    prob.set_batch_params([0], cs[None, :])
+    integ = ocs.RK4Integrator(tspan)
+    ocs.fb_sweep_dev(prob, integ, x0)  # warm-up (allocations, tables)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        r = ocs.fb_sweep_dev(prob, integ, x0)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    sw = r["sweeps"].cpu().numpy()
+    iters = int(np.where(sw > 0, sw, 50).sum())
+    return {"value": iters / dt, "unit": "fb_sweep iters/s (instance-sweeps)", "batch": batch, "n_steps": NSTEPS,
+            "seconds_per_solve": dt, "sweeps_min": int(sw[sw > 0].min()) if (sw > 0).any() else 0,
+            "sweeps_max": int(sw.max()), "fraction_converged": float((sw > 0).mean()),
+            "batch_sweeps_per_s": float(sw.max()) / dt}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -88,6 +116,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=BATCH, help="trajectories per GPU (default: BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fb-sweep", action="store_true", help="skip the secondary fb_sweep iters/sec measurement")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -130,7 +159,7 @@ def main():
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
         if k is not None:
             ev[k][2].record()
-        if world > 1:
+        if world > 1:  # the one collective of the path: all-reduce(SUM) of the objective over the shards
             torch.sum(J, dim=0, keepdim=True, out=Jsum)
             dist.all_reduce(Jsum)
 
@@ -200,6 +229,8 @@ def main():
                         "pass_pair_frac": (bytes_fwd + bytes_bwd) / (t_fwd + t_bwd) / 1e9 / HBM_PEAK_GBPS},
             "finite": ok,
         }
+        if not args.no_fb_sweep:
+            line["fb_sweep"] = fb_sweep_metric(ocs, dev)
         if not args.no_cpu_baseline and world == 1:
             cb, ref = cpu_baseline(tspan, x0_h, u_h)
             line["cpu_baseline"] = cb

@@ -194,6 +194,9 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double *x
  * device pointers, rows*cols doubles per trajectory. */
 int ocs_to_batch_minor_dev(const double *src, double *dst, int per_traj, int batch, void *stream);
 int ocs_to_traj_major_dev(const double *src, double *dst, int per_traj, int batch, void *stream);
+/* dst[0..n) = src[0..n) with this path's access width (8 B per lane): the known-byte-count launch used
+ * to calibrate the rocprofv3 HBM counters (scripts/calibrate_traffic.py). */
+int ocs_copy_dev(const double *src, double *dst, long n, void *stream);
 
 #ifdef __cplusplus
 }

@@ -13,3 +13,4 @@ from .control import Control, PWLinearControl, PWConstantControl, ChebyshevContr
 from .interp import vectorInterpolant, heval  # noqa: F401
 from .solvers import nlp_objective, nlp_objective_dev, single_shooting  # noqa: F401
 from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, compute_x_lam, compute_x_lam_J  # noqa: F401
+from . import distributed  # noqa: F401

@@ -80,6 +80,7 @@ _SIG = {
     "ocs_compute_x_lam_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "ocs_fb_sweep": (C.c_int, [vp, vp, C.c_int, dp, vp, dp, dp, dp, dp, dp, dp, ip, dp]),
     "ocs_fb_sweep_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ocs_copy_dev": (C.c_int, [vp, vp, C.c_long, vp]),
     "ocs_to_batch_minor_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "ocs_to_traj_major_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
 }

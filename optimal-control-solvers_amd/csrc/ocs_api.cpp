@@ -373,6 +373,12 @@ int ocs_compute_adjoints(ocs_integrator g, ocs_problem p, int batch, const doubl
   return OCS_OK;
 }
 
+int ocs_copy_dev(const double* src, double* dst, long n, void* stream) {
+  if (!src || !dst || n < 1) return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(require_device());
+  LAUNCH_TRY(launch_copy8(src, dst, (size_t)n, (hipStream_t)stream));
+  return OCS_OK;
+}
 int ocs_to_batch_minor_dev(const double* src, double* dst, int per_traj, int batch, void* stream) {
   if (!src || !dst || per_traj < 1 || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(require_device());

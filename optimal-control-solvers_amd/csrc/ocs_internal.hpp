@@ -54,6 +54,7 @@ int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const d
 // layout helpers; per = doubles per trajectory
 int launch_to_batch_minor(const double* src, double* dst, int per, int batch, hipStream_t s);
 int launch_to_traj_major(const double* src, double* dst, int per, int batch, hipStream_t s);
+int launch_copy8(const double* src, double* dst, size_t n, hipStream_t s);
 // number of non-finite entries of v[0..n) is added to *count (device int)
 int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s);
 

@@ -527,6 +527,16 @@ __global__ __launch_bounds__(256) void k_transpose(const double* __restrict__ sr
   }
 }
 
+// straight 8-byte-per-lane copy: the known-byte-count reference for calibrating the HBM counters
+__global__ __launch_bounds__(256) void k_copy8(const double* __restrict__ src, double* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = src[i];
+}
+int launch_copy8(const double* src, double* dst, size_t n, hipStream_t s) {
+  k_copy8<<<dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s>>>(src, dst, n);
+  return hip_rc(hipGetLastError());
+}
+
 __global__ void k_count_nonfinite(const double* __restrict__ v, int n, int* __restrict__ count) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const bool bad = (i < n) && !isfinite(v[i]);
