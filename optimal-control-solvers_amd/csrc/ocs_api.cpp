@@ -226,6 +226,13 @@ int ocs_integrator_destroy(ocs_integrator g) {
   delete g;
   return OCS_OK;
 }
+int ocs_integrator_set_mapping(ocs_integrator g, int mapping) {
+  if (!g) return fail(OCS_ERR_INVALID, "null integrator");
+  if (mapping < MAP_AUTO || mapping > MAP_ROWSPLIT) return fail(OCS_ERR_INVALID, "mapping must be 0, 1 or 2");
+  g->mapping = mapping;
+  if (g->leg2) g->leg2->mapping = mapping;
+  return OCS_OK;
+}
 int ocs_integrator_nsteps(ocs_integrator g, int* nsteps) {
   if (!g || !nsteps) return fail(OCS_ERR_INVALID, "null argument");
   *nsteps = g->N;
@@ -253,7 +260,9 @@ static int leg_forward(ocs_integrator_s* g, ocs_problem_s* p, int batch, const d
     ck = g->d_ck.d();
   }
   g->ck = nullptr;
-  LAUNCH_TRY(launch_forward(describe(p), describe(g), batch, x0, u, ck, J, o, s));
+  FwdOpts om = o;
+  om.mapping = g->mapping;
+  LAUNCH_TRY(launch_forward(describe(p), describe(g), batch, x0, u, ck, J, om, s));
   g->ck = ck;
   g->ck_batch = batch;
   g->ck_prob = p;
@@ -290,6 +299,7 @@ int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const d
   hipStream_t s = (hipStream_t)stream;
   OCS_TRY(bind_problem(g, p, batch, s));
   BwdOpts o;
+  o.mapping = g->mapping;
   o.lam0 = g->want_lam0;
   if (g->kind == 1) {
     // RK4InfiniteIntegrator.m:27-30: lam2 = leg2.adjoints(uStar); [lam,dJdu] = leg1.adjoints(u, lam2(:,1))

@@ -20,6 +20,10 @@ __device__ static inline uniform_ptr as_uniform(const double* p) { return (unifo
 // single s_load_dwordx16 (NTC = 1) fetches it, issued one step ahead of its use:
 //   REC[i] = { h, h/2, h/6, h/3, tc(t_2i)[NTC], tc(t_2i+1)[NTC], tc(t_2i+2)[NTC], pad }
 __host__ __device__ constexpr int rec_stride(int ntc) { return ((4 + 3 * ntc + 7) / 8) * 8; }
+// The table carries kRecPad extra records before step 0 and after step N-1 (copies of the edge
+// records) so that the kernels can keep a ring of prefetched records in flight by just walking a
+// pointer, without clamping the index at either end.
+constexpr int kRecPad = 4;
 
 template <int NTC>
 struct StepRec {
@@ -32,8 +36,7 @@ struct StepRec {
 // prefetch would always be waited for together with the record that is needed (measured:
 // +40 % time per step).
 template <int NTC>
-__device__ static inline StepRec<NTC> load_rec(const double* REC, int i) {
-  const double* q = REC + (size_t)i * rec_stride(NTC);
+__device__ static inline StepRec<NTC> load_rec(const double* q) {
   StepRec<NTC> r;
   r.h = q[0];
   r.hh = q[1];

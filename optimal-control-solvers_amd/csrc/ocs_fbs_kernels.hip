@@ -149,10 +149,14 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
     for (int k = 0; k < NS; ++k) out[k] = -g[k];
   };
 
+  static_assert(PF <= kRecPad, "record ring deeper than the table padding");
   Rec rq[PF];
+  const double* recp = a.REC + (size_t)(N - 1) * rec_stride(NTC);  // walks down; padded before step 0
 #pragma unroll
-  for (int q = 0; q < PF; ++q) rq[q] = load_rec<NTC>(a.REC, N - 1 - q > 0 ? N - 1 - q : 0);
-  int inext = N - 1 - PF;
+  for (int q = 0; q < PF; ++q) {
+    rq[q] = load_rec<NTC>(recp);
+    recp -= rec_stride(NTC);
+  }
   // node/midpoint samples of step i-1 are requested while step i is computed
   double xA[NS], xM[NS], uA[NC], uM[NC];
   auto fetch = [&](int i) OCS_INLINE {
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
     const Rec r = rq[0];
 #pragma unroll
     for (int q = 0; q + 1 < PF; ++q) rq[q] = rq[q + 1];
-    rq[PF - 1] = load_rec<NTC>(a.REC, inext > 0 ? inext : 0);
-    --inext;
+    rq[PF - 1] = load_rec<NTC>(recp);
+    recp -= rec_stride(NTC);
     double cxA[NS], cxM[NS], cuA[NC], cuM[NC];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
@@ -395,7 +399,7 @@ int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const dou
 
 template <class P>
 static void run_costate(const CostateArgs& a, hipStream_t s) {
-  k_costate<P, 3><<<dim3((a.batch + 63) / 64), dim3(64), 0, s>>>(a);
+  k_costate<P, 4><<<dim3((a.batch + 63) / 64), dim3(64), 0, s>>>(a);
 }
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* usel, long long udelta, double* lam, hipStream_t s) {

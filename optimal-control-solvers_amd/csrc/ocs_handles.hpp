@@ -116,6 +116,8 @@ void ocs_fbs_state_free(ocs_fbs_state* s);
 struct ocs_integrator_s {
   using DevBuf = ocs::DevBuf;
   ocs_fbs_state* fbs = nullptr;
+  int rec_stride = 8;  // doubles per step record of the bound problem
+  int mapping = 0;  // ocs::Mapping requested through ocs_integrator_set_mapping (0 = automatic)
   int kind = 0;  // 0 RK4Integrator, 1 RK4InfiniteIntegrator (then `leg2` and `ustar` are set)
   ocs_integrator_s* leg2 = nullptr;   // integrator2 of RK4InfiniteIntegrator.m:13-14
   std::vector<double> ustar;          // uStar (nC)
@@ -197,7 +199,7 @@ inline GridDesc describe(const ocs_integrator_s* g) {
   d.T = g->d_T.d();
   d.TC = g->d_TC.d();
   d.TU = g->d_TU.d();
-  d.REC = g->d_REC.d();
+  d.REC = g->d_REC.d() ? g->d_REC.d() + (size_t)rec_pad_host() * g->rec_stride : nullptr;
   return d;
 }
 
@@ -213,7 +215,8 @@ inline int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStr
     const int ntu = functor_ntu(p->functor, p->nS);
     OCS_TRY(g->d_TC.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * ntc));
     OCS_TRY(g->d_TU.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * (ntu > 0 ? ntu : 1)));
-    OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)g->N * rec_stride_host(ntc)));
+    g->rec_stride = rec_stride_host(ntc);
+    OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)(g->N + 2 * rec_pad_host()) * g->rec_stride));
     LAUNCH_TRY(launch_tcoef(describe(p), describe(g), s));
     g->tc_prob = p;
     g->tc_version = p->version;

@@ -32,13 +32,24 @@ struct GridDesc {
 // Device-native layouts (batch-minor): x0 [nS][B], u [2N+1][nC][B], x [N+1][nAug][B],
 // lam [N+1][nAug][B], dJdu [2N+1][nC][B], J [B], lamT [nAug][B].
 int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s);
+// mapping of the serial RK4 kernels: lane-per-trajectory (ocs_kernels.hip) or row-split
+// (ocs_rowsplit_kernels.hip, row-separable problems only)
+enum Mapping : int { MAP_AUTO = 0, MAP_LANE = 1, MAP_ROWSPLIT = 2 };
+bool rowsplit_supported(Functor f, int nS, int nC);
+int launch_forward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
+                      double* x, double* J, hipStream_t s);
+int launch_backward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                       const double* lamT, double* lam, double* dJdu, double* lam0, hipStream_t s);
+
 struct FwdOpts {
+  int mapping = MAP_AUTO;
   bool uconst = false;          // u is a device [nC] vector shared by all grid points and trajectories
   const double* Jadd = nullptr; // J = Jadd + x(end,end)
   const int* usel = nullptr;    // per-trajectory control buffer select (fb_sweep)
   long long udelta = 0;
 };
 struct BwdOpts {
+  int mapping = MAP_AUTO;
   bool uconst = false;
   double* lam0 = nullptr;       // [nAug][B]: lam(:,1)
   const int* usel = nullptr;
@@ -94,6 +105,7 @@ bool functor_supported(Functor f, int nS, int nC);
 int functor_ntc(Functor f, int nS);
 int functor_ntu(Functor f, int nS);
 int rec_stride_host(int ntc);
+int rec_pad_host();
 unsigned functor_tc_param_mask(Functor f, int nS);
 
 }  // namespace ocs

@@ -43,11 +43,13 @@ __global__ void k_tcoef(int nT, const double* __restrict__ T, const double* __re
 // ---------------------------------------------------------------------------------------
 // per-step record table (layout: ocs_device_common.hpp)
 // ---------------------------------------------------------------------------------------
+// REC points at the record of step 0; records -kRecPad..-1 and N..N+kRecPad-1 are edge copies.
 __global__ void k_build_rec(int N, int ntc, int rs, const double* __restrict__ HT,
                             const double* __restrict__ TC, double* __restrict__ REC) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= N) return;
-  double* r = REC + (size_t)i * rs;
+  const int ip = blockIdx.x * blockDim.x + threadIdx.x - kRecPad;
+  if (ip >= N + kRecPad) return;
+  const int i = ip < 0 ? 0 : (ip >= N ? N - 1 : ip);
+  double* r = REC + (long long)ip * rs;
   for (int k = 0; k < 4; ++k) r[k] = HT[4 * i + k];
   for (int k = 0; k < 3 * ntc; ++k) r[4 + k] = TC[(size_t)(2 * i) * ntc + k];  // three consecutive grid points
   for (int k = 4 + 3 * ntc; k < rs; ++k) r[k] = 0.0;
@@ -164,16 +166,20 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
   };
   // uniform step records are fetched PF steps ahead (scalar loads miss the scalar cache on
   // every new 64-byte record, so one step of lead does not cover the L2 round trip)
+  static_assert(PF <= kRecPad, "record ring deeper than the table padding");
   Rec rq[PF];
+  const double* recp = REC;  // walks forward one record per step; the table is padded past step N-1
 #pragma unroll
-  for (int q = 0; q < PF; ++q) rq[q] = load_rec<NTC>(REC, q < N ? q : N - 1);
-  int inext = PF;
+  for (int q = 0; q < PF; ++q) {
+    rq[q] = load_rec<NTC>(recp);
+    recp += rec_stride(NTC);
+  }
   auto next_rec = [&]() OCS_INLINE {
     const Rec cur = rq[0];
 #pragma unroll
     for (int q = 0; q + 1 < PF; ++q) rq[q] = rq[q + 1];
-    rq[PF - 1] = load_rec<NTC>(REC, inext < N ? inext : N - 1);
-    ++inext;
+    rq[PF - 1] = load_rec<NTC>(recp);
+    recp += rec_stride(NTC);
     return cur;
   };
   auto run_chunk = [&](const double (&src)[2 * CH][NC]) OCS_INLINE {
@@ -366,16 +372,20 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
   };
 
   const int nch = UCONST ? 0 : N / CH;
+  static_assert(PF <= kRecPad, "record ring deeper than the table padding");
   Rec rq[PF];
+  const double* recp = REC + (size_t)(N - 1) * rec_stride(NTC);  // walks down; padded before step 0
 #pragma unroll
-  for (int q = 0; q < PF; ++q) rq[q] = load_rec<NTC>(REC, N - 1 - q > 0 ? N - 1 - q : 0);
-  int inext = N - 1 - PF;
+  for (int q = 0; q < PF; ++q) {
+    rq[q] = load_rec<NTC>(recp);
+    recp -= rec_stride(NTC);
+  }
   auto next_rec = [&]() OCS_INLINE {
     const Rec cur = rq[0];
 #pragma unroll
     for (int q = 0; q + 1 < PF; ++q) rq[q] = rq[q + 1];
-    rq[PF - 1] = load_rec<NTC>(REC, inext > 0 ? inext : 0);
-    --inext;
+    rq[PF - 1] = load_rec<NTC>(recp);
+    recp -= rec_stride(NTC);
     return cur;
   };
   // remainder steps at the top of the grid first (i = N-1 .. nch*CH), direct loads
@@ -584,29 +594,42 @@ static void run_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
 int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
   OCS_DISPATCH_LOGISTIC(p.nS, run_tcoef<P>(p, g, s));
   const int ntc = functor_ntc(p.functor, p.nS);
-  k_build_rec<<<dim3((g.N + 255) / 256), dim3(256), 0, s>>>(g.N, ntc, rec_stride(ntc), g.HT, g.TC, g.REC);
+  k_build_rec<<<dim3((g.N + 2 * kRecPad + 255) / 256), dim3(256), 0, s>>>(g.N, ntc, rec_stride(ntc), g.HT, g.TC, g.REC);
   return hip_rc(hipGetLastError());
 }
 int rec_stride_host(int ntc) { return rec_stride(ntc); }
+int rec_pad_host() { return kRecPad; }
 
 constexpr int kChunk = 4;
-#ifndef OCS_PF
-#define OCS_PF 3
-#endif
-constexpr int kPF = OCS_PF;  // step records in flight
+// step records in flight: a divisor of 2*kChunk so the ring needs no register rotation at the loop
+// back-edge; deeper for the small problems, whose register budget is loose and which run with few waves
+template <class P>
+constexpr int pf_of() { return P::NS <= 2 ? 4 : 3; }
 
 template <class P>
 static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
   const dim3 grid((a.batch + 63) / 64), block(64);
   if (uconst)
-    k_forward<P, kChunk, kPF, true, true><<<grid, block, 0, s>>>(a);
+    k_forward<P, kChunk, pf_of<P>(), true, true><<<grid, block, 0, s>>>(a);
   else if (a.x)
-    k_forward<P, kChunk, kPF, true, false><<<grid, block, 0, s>>>(a);
+    k_forward<P, kChunk, pf_of<P>(), true, false><<<grid, block, 0, s>>>(a);
   else
-    k_forward<P, kChunk, kPF, false, false><<<grid, block, 0, s>>>(a);
+    k_forward<P, kChunk, pf_of<P>(), false, false><<<grid, block, 0, s>>>(a);
 }
+// Row-split pays while the lane-per-trajectory kernel would leave most SIMDs idle (fewer waves than
+// SIMDs); beyond that the lane mapping has the lower instruction count per trajectory and the lower
+// register pressure, and the passes turn HBM-bound anyway.
+static bool use_rowsplit(const ProblemDesc& p, int batch, int mapping, bool plain) {
+  if (!plain || mapping == MAP_LANE || !rowsplit_supported(p.functor, p.nS, p.nC)) return false;
+  if (mapping == MAP_ROWSPLIT) return true;
+  return batch <= 8192;
+}
+
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
+  if (use_rowsplit(p, batch, o.mapping, !o.uconst && !o.Jadd && !o.usel))
+    return launch_forward_rs(p, g, batch, x0, u, x, J, s);
+  if (o.mapping == MAP_ROWSPLIT) return -1;
   if (o.uconst && !x) return -1;
   const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.usel, o.udelta};
   OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, o.uconst, s));
@@ -617,16 +640,19 @@ template <class P>
 static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
   const dim3 grid((a.batch + 63) / 64), block(64);
   if (uconst)
-    k_backward<P, kChunk, kPF, false, false, true><<<grid, block, 0, s>>>(a);
+    k_backward<P, kChunk, pf_of<P>(), false, false, true><<<grid, block, 0, s>>>(a);
   else if (a.lam && a.dJdu)
-    k_backward<P, kChunk, kPF, true, true, false><<<grid, block, 0, s>>>(a);
+    k_backward<P, kChunk, pf_of<P>(), true, true, false><<<grid, block, 0, s>>>(a);
   else if (a.lam)
-    k_backward<P, kChunk, kPF, true, false, false><<<grid, block, 0, s>>>(a);
+    k_backward<P, kChunk, pf_of<P>(), true, false, false><<<grid, block, 0, s>>>(a);
   else
-    k_backward<P, kChunk, kPF, false, true, false><<<grid, block, 0, s>>>(a);
+    k_backward<P, kChunk, pf_of<P>(), false, true, false><<<grid, block, 0, s>>>(a);
 }
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
+  if (use_rowsplit(p, batch, o.mapping, !o.uconst && !o.usel))
+    return launch_backward_rs(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
+  if (o.mapping == MAP_ROWSPLIT) return -1;
   if (o.uconst ? (lam || dJdu || !o.lam0) : (!lam && !dJdu)) return -1;
   const BwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, o.lam0, o.usel, o.udelta};
   OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, o.uconst, s));

@@ -8,8 +8,8 @@
 // __device__ functions that the RK4 kernels are instantiated on.  Everything that
 // depends on t only (exp(-r t) in tests/TestOCProblem.m:25,31,37) is hoisted into a
 // per-grid-point table TC filled once per (integrator, problem) pair by tcoef(): it is
-// wave-uniform, so the kernels read it with scalar loads and keep transcendental
-// calls off the serial RK4 recursion.
+// wave-uniform and reaches the kernels through the per-step record table, which keeps
+// transcendental calls off the serial RK4 recursion.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -83,6 +83,41 @@ struct LogisticK {
     for (int k = 1; k < NS; ++k) s -= v[k];
     g[0] = __builtin_fma(2.0 * p.c * tc[0] * u[0], v[NS], s);
   }
+  // ---- row-separable form (row-split mapping, ocs_rowsplit_kernels.hip) --------------------
+  // Row k of F depends on y_k and u only, and the objective integrand is a sum of per-row terms
+  // q_k(y_k, u) (the control cost c u^2 is charged to row 0), so a group of NS lanes can own one
+  // trajectory, one state row per lane, and meet only in the running-cost / dJdu reductions.
+  static constexpr bool ROW_SEPARABLE = true;
+  struct RowPar {
+    double m;   // m_r
+    double cw;  // c for row 0, 0 for the other rows
+  };
+  template <class Get>
+  __device__ static inline RowPar load_row(Get get, int r) {
+    RowPar rp;
+    rp.m = get(2);
+#pragma unroll
+    for (int k = 1; k < NS; ++k) rp.m = (r == k) ? get(2 + k) : rp.m;
+    rp.cw = (r == 0) ? get(0) : 0.0;
+    return rp;
+  }
+  // row r of F (states):  y (m_r - y) - u
+  __device__ static inline double row_f(double y, double u, const RowPar& rp) {
+    return __builtin_fma(y, rp.m - y, -u);
+  }
+  // this row's share of the objective integrand, without the e^{-rt} factor:  y^2 + cw u^2
+  __device__ static inline double row_q(double y, double u2, const RowPar& rp) {
+    return __builtin_fma(rp.cw, u2, y * y);
+  }
+  // row r of (dF/dy)' v:  (m_r - 2 y) v_r + ev y,   ev = 2 e^{-rt} v_cost
+  __device__ static inline double row_dfdx(double y, double v, double ev, const RowPar& rp) {
+    return __builtin_fma(__builtin_fma(-2.0, y, rp.m), v, ev * y);
+  }
+  // this row's share of (dF/du)' v:  -v_r + cw u ev,   cu = cw u
+  __device__ static inline double row_dfdu(double cu, double v, double ev) {
+    return __builtin_fma(cu, ev, -v);
+  }
+
   // Gen-1 ControlChar through the A9 adapter (make_from_symbolic.m:19-23,111):
   //   dHdu = -sum(lam) + 2 c e^{-rt} u = 0  ->  u = sum(lam) e^{rt} / (2c), clamped to the bounds.
   __device__ static inline void control_char(const double* tu, const double* x, const double* lam,

@@ -63,6 +63,12 @@ class RK4Integrator(Integrator):
             lib.ocs_integrator_destroy(h)
             self._h = None
 
+    def set_mapping(self, mapping):
+        """Thread mapping of the RK4 kernels: "auto", "lane" (lane per trajectory) or "rowsplit"."""
+        code = {"auto": 0, "lane": 1, "rowsplit": 2}[mapping]
+        check(lib.ocs_integrator_set_mapping(self._h, code))
+        return self
+
     # ---- host path (MATLAB shapes) -------------------------------------------------
     def compute_states(self, prob, x0, u):
         """[x, J] = compute_states(obj, prob, x0, u)   RK4Integrator.m:28-56.

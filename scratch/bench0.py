@@ -1,4 +1,4 @@
-import sys, time, numpy as np, torch
+import os, sys, time, numpy as np, torch
 sys.path.insert(0, '.')
 import __graft_entry__ as g
 ocs = g.load_package()
@@ -6,7 +6,7 @@ dev = torch.device('cuda:0')
 def run(nS, N, batch, reps=10):
     m = [3.0, 2.5, 2.0, 1.5][:nS]
     prob = ocs.LogisticProblem(m, 1.5, 0.05, [[0.0, 1.0]])
-    integ = ocs.RK4Integrator(np.linspace(0, 10, N + 1))
+    integ = ocs.RK4Integrator(np.linspace(0, 10, N + 1)).set_mapping(os.environ.get('MAPPING','auto'))
     x0 = torch.ones((nS, batch), dtype=torch.float64, device=dev)
     u = 0.05 + 0.4 * torch.rand((2 * N + 1, 1, batch), dtype=torch.float64, device=dev)
     x = torch.empty((N + 1, nS + 1, batch), dtype=torch.float64, device=dev)

@@ -88,6 +88,38 @@ def test_states_and_adjoints_match_oracle(ocs, oracle, nS, N, batch, T):
     assert np.all(lam[-1] == 1.0)  # SURVEY KAT 3: exact
 
 
+@pytest.mark.parametrize("nS,N,batch,T", [(4, 200, 130, 10.0), (2, 3, 64, 0.2), (2, 9, 129, 0.5), (4, 1, 5, 0.05),
+                                          (4, 37, 1, 2.0), (2, 1000, 40, 10.0)])
+@pytest.mark.parametrize("mapping", ["lane", "rowsplit"])
+def test_both_mappings_match_oracle(ocs, oracle, nS, N, batch, T, mapping):
+    # the row-split kernels (one state row per lane) must give the same answers as lane-per-trajectory,
+    # including explicit lamT, lam-only / dJdu-only variants and partially filled last waves
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    tspan, x0, u = _inputs(oracle, nS, N, batch, seed=300 + nS + N, T=T)
+    pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    g = ocs.RK4Integrator(tspan).set_mapping(mapping)
+    x, J = g.compute_states(pg, x0, u)
+    lam, dJdu = g.compute_adjoints(pg, u)
+    ref = oracle.batch_states_adjoints(po, tspan, x0, u)
+    assert relerr(x, ref["x"]) < RTOL and relerr(J, ref["J"]) < RTOL
+    assert relerr(lam, ref["lam"]) < RTOL and relerr(dJdu, ref["dJdu"]) < RTOL
+    assert np.array_equal(x[-1, -1, :], J) and np.all(lam[-1] == 1.0)
+    lamT = np.random.default_rng(1).normal(size=(nS + 1, batch))
+    lam2 = g.compute_adjoints(pg, u, lamT, nargout=1)
+    go = oracle.RK4Integrator(tspan)
+    for b in sorted({0, batch - 1}):
+        go.compute_states(po, x0[:, b], u[:, :, b])
+        assert relerr(lam2[:, :, b], go.compute_adjoints(po, u[:, :, b], lamT[:, b], want_dJdu=False)) < RTOL
+
+
+def test_rowsplit_rejects_unsupported(ocs):
+    pg = ocs.TestOCProblem(P, BOUNDS)  # nS = 1: nothing to split
+    g = ocs.RK4Integrator(np.linspace(0, 1, 11)).set_mapping("rowsplit")
+    with pytest.raises(ocs.OcsError) as e:
+        g.compute_states(pg, [1.0], np.zeros((1, 21)))
+    assert e.value.code == -6
+
+
 def test_single_trajectory_shapes_and_nonuniform_grid(ocs, oracle):
     # batch = 1 must reproduce the reference's shapes exactly; h = diff(tspan) may be non-uniform
     tspan = np.sort(np.concatenate([[0.0, 6.0], np.random.default_rng(8).uniform(0, 6, 49)]))
