@@ -228,7 +228,7 @@ int ocs_integrator_destroy(ocs_integrator g) {
 }
 int ocs_integrator_set_mapping(ocs_integrator g, int mapping) {
   if (!g) return fail(OCS_ERR_INVALID, "null integrator");
-  if (mapping < MAP_AUTO || mapping > MAP_ROWSPLIT) return fail(OCS_ERR_INVALID, "mapping must be 0, 1 or 2");
+  if (mapping < MAP_AUTO || mapping > MAP_PIPELINE) return fail(OCS_ERR_INVALID, "mapping must be 0..3");
   g->mapping = mapping;
   if (g->leg2) g->leg2->mapping = mapping;
   return OCS_OK;

@@ -627,6 +627,10 @@ static bool use_rowsplit(const ProblemDesc& p, int batch, int mapping, bool plai
 
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
+  if (o.mapping == MAP_PIPELINE) {
+    if (o.uconst || o.Jadd || o.usel || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
+    return launch_forward_pl(p, g, batch, x0, u, x, J, s);
+  }
   if (use_rowsplit(p, batch, o.mapping, !o.uconst && !o.Jadd && !o.usel))
     return launch_forward_rs(p, g, batch, x0, u, x, J, s);
   if (o.mapping == MAP_ROWSPLIT) return -1;
@@ -650,7 +654,7 @@ static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
 }
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
-  if (use_rowsplit(p, batch, o.mapping, !o.uconst && !o.usel))
+  if (use_rowsplit(p, batch, o.mapping == MAP_PIPELINE ? MAP_AUTO : o.mapping, !o.uconst && !o.usel))
     return launch_backward_rs(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
   if (o.mapping == MAP_ROWSPLIT) return -1;
   if (o.uconst ? (lam || dJdu || !o.lam0) : (!lam && !dJdu)) return -1;

@@ -30,4 +30,4 @@ import os
 batches = [int(b) for b in os.environ.get("BATCHES", "4096,16384,65536,262144").split(",")]
 for nS in (4, 1):
     for batch in batches:
-        run(nS, 1000, batch)
+        run(nS, int(os.environ.get('NSTEPS','1000')), batch)
