@@ -16,10 +16,11 @@ __device__ static inline uniform_ptr as_uniform(const double* p) { return (unifo
 // ---------------------------------------------------------------------------------------
 // per-step record table
 // ---------------------------------------------------------------------------------------
-// Everything wave-uniform that step i needs sits in one 64-byte-aligned record so that a
-// single s_load_dwordx16 (NTC = 1) fetches it, issued one step ahead of its use:
-//   REC[i] = { h, h/2, h/6, h/3, tc(t_2i)[NTC], tc(t_2i+1)[NTC], tc(t_2i+2)[NTC], pad }
-__host__ __device__ constexpr int rec_stride(int ntc) { return ((4 + 3 * ntc + 7) / 8) * 8; }
+// Everything wave-uniform that step i needs sits in one 64-byte-aligned record:
+//   REC[i] = { h, h/2, h/6, h/3, tc(t_2i)[NTC], tc(t_2i+1)[NTC], tc(t_2i+2)[NTC], pad | sc[8] }
+__host__ __device__ constexpr int rec_sc_offset(int ntc) { return ((4 + 3 * ntc + 7) / 8) * 8; }
+// ... followed by a block of 8 problem-defined step constants (P::step_consts; used by the pipeline kernels)
+__host__ __device__ constexpr int rec_stride(int ntc) { return rec_sc_offset(ntc) + 8; }
 // The table carries kRecPad extra records before step 0 and after step N-1 (copies of the edge
 // records) so that the kernels can keep a ring of prefetched records in flight by just walking a
 // pointer, without clamping the index at either end.

@@ -44,15 +44,21 @@ __global__ void k_tcoef(int nT, const double* __restrict__ T, const double* __re
 // per-step record table (layout: ocs_device_common.hpp)
 // ---------------------------------------------------------------------------------------
 // REC points at the record of step 0; records -kRecPad..-1 and N..N+kRecPad-1 are edge copies.
-__global__ void k_build_rec(int N, int ntc, int rs, const double* __restrict__ HT,
-                            const double* __restrict__ TC, double* __restrict__ REC) {
+template <class P>
+__global__ void k_build_rec(int N, const double* __restrict__ HT, const double* __restrict__ TC,
+                            double* __restrict__ REC) {
+  constexpr int NTC = P::NTC, RS = rec_stride(NTC), SCO = rec_sc_offset(NTC);
   const int ip = blockIdx.x * blockDim.x + threadIdx.x - kRecPad;
   if (ip >= N + kRecPad) return;
   const int i = ip < 0 ? 0 : (ip >= N ? N - 1 : ip);
-  double* r = REC + (long long)ip * rs;
+  double* r = REC + (long long)ip * RS;
   for (int k = 0; k < 4; ++k) r[k] = HT[4 * i + k];
-  for (int k = 0; k < 3 * ntc; ++k) r[4 + k] = TC[(size_t)(2 * i) * ntc + k];  // three consecutive grid points
-  for (int k = 4 + 3 * ntc; k < rs; ++k) r[k] = 0.0;
+  for (int k = 0; k < 3 * NTC; ++k) r[4 + k] = TC[(size_t)(2 * i) * NTC + k];  // three consecutive grid points
+  for (int k = 4 + 3 * NTC; k < RS; ++k) r[k] = 0.0;
+  double sc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  static_assert(P::NSC <= 8, "at most 8 step constants");
+  P::step_consts(r[2], r[3], r + 4, r + 4 + NTC, r + 4 + 2 * NTC, sc);
+  for (int k = 0; k < P::NSC; ++k) r[SCO + k] = sc[k];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -590,11 +596,10 @@ template <class P>
 static void run_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
   const int nT = 2 * g.N + 1;
   k_tcoef<P><<<dim3((nT + 255) / 256), dim3(256), 0, s>>>(nT, g.T, p.ps, g.TC, g.TU);
+  k_build_rec<P><<<dim3((g.N + 2 * kRecPad + 255) / 256), dim3(256), 0, s>>>(g.N, g.HT, g.TC, g.REC);
 }
 int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
   OCS_DISPATCH_LOGISTIC(p.nS, run_tcoef<P>(p, g, s));
-  const int ntc = functor_ntc(p.functor, p.nS);
-  k_build_rec<<<dim3((g.N + 2 * kRecPad + 255) / 256), dim3(256), 0, s>>>(g.N, ntc, rec_stride(ntc), g.HT, g.TC, g.REC);
   return hip_rc(hipGetLastError());
 }
 int rec_stride_host(int ntc) { return rec_stride(ntc); }
@@ -654,7 +659,11 @@ static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
 }
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
-  if (use_rowsplit(p, batch, o.mapping == MAP_PIPELINE ? MAP_AUTO : o.mapping, !o.uconst && !o.usel))
+  if (o.mapping == MAP_PIPELINE) {
+    if (o.uconst || o.usel || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
+    return launch_backward_pl(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
+  }
+  if (use_rowsplit(p, batch, o.mapping, !o.uconst && !o.usel))
     return launch_backward_rs(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
   if (o.mapping == MAP_ROWSPLIT) return -1;
   if (o.uconst ? (lam || dJdu || !o.lam0) : (!lam && !dJdu)) return -1;

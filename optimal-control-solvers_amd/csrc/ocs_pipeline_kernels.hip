@@ -10,6 +10,8 @@
 // run concurrently on the SIMDs of one CU and hand data to each other through LDS in blocks of D
 // steps (one LDS-only barrier per block):
 //
+//   (roles are cut where the hand-off is narrow: LDS stores cost a lone wave ~13 cycles per 512 B, as
+//    much as two fp64 instructions, so R hands over 3 values per step and A 3, not 8 and 4)
 //   forward   wave M: memory wave.  Streams control samples and step records HBM -> LDS with LDS-DMA
 //                     (global_load_lds_dwordx4, 1 KiB per instruction, no VGPR staging), Q blocks
 //                     ahead of the compute waves; it is the only wave that waits on loads.
@@ -18,8 +20,8 @@
 //             wave C: integrates the objective from the published stage states, reduces it over
 //                     the rows of a trajectory (DPP) and stores the cost row / J.
 //   backward  wave M: streams checkpoints, control samples and records.
-//             wave R: recomputes the stage states from the checkpoints, publishes them.
-//             wave A: the adjoint recursion (dJdk, lam); stores lam; publishes k1..k4.
+//             wave R: recomputes the stage states Y2..Y4 from the checkpoints, publishes them.
+//             wave A: the adjoint recursion (dJdk, lam); stores lam; publishes k1, k2+k3, k4.
 //             wave D: assembles the dJdu columns from k1..k4, reduces over rows, stores them.
 //
 // The serial critical path per step shrinks to the longest role, and no compute wave ever waits for
@@ -30,6 +32,10 @@
 #include "ocs_device_common.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_problems.hpp"
+#ifdef OCS_PL_STAMPS
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace ocs {
 
@@ -72,17 +78,31 @@ __device__ static inline void wait_blocks(int blocks) {
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * LPB) : "memory");
 }
 
-template <int G>
+template <int G, bool BWD>
 struct PLCfg {
-  static constexpr int D = (G == 4) ? 16 : 8;   // steps per hand-off block
-  static constexpr int TPW = 64 / G;            // trajectories per workgroup
-  static constexpr int Q = 3;                   // blocks the memory wave runs ahead (wait_blocks handles <= 2 younger)
-  static constexpr int NSLOT = Q + 2;           // input ring slots (see the schedule below)
-  static constexpr int REC_DBL = D * 8;         // records of a block (NTC = 1: 8 doubles each)
-  static constexpr int U_DBL = 2 * D * TPW;     // control samples of a block
-  static constexpr int NU = U_DBL / 128;        // DMA instructions for them
-  static_assert(U_DBL % 128 == 0, "a block of control samples must be whole DMA instructions");
+  static constexpr int D = (!BWD && G == 4) ? 16 : 8;  // steps per hand-off block
+  static constexpr int TPW = 64 / G;                   // trajectories per workgroup
+  static constexpr int Q = 3;                          // blocks the memory wave runs ahead (wait_blocks: <= 2 younger)
+  static constexpr int LAG = BWD ? 2 : 1;              // intervals between the first and the last reader of a slot
+  static constexpr int NSLOT = Q + LAG + 1;            // input ring slots (see the schedules below)
+  static constexpr int RS = rec_stride(1);             // doubles per step record (NTC = 1)
+  static constexpr int SCO = rec_sc_offset(1);         // offset of the step constants in a record
+  static constexpr int REC_DBL = D * RS;               // records of a block
+  static constexpr int NREC = REC_DBL / 128;           // DMA instructions for them
+  static constexpr int U_DBL = 2 * D * TPW;            // control samples of a block
+  static constexpr int NU = U_DBL / 128;
+  static constexpr int X_DBL = BWD ? D * 64 : 0;       // checkpoint rows of a block (backward only)
+  static constexpr int NX = X_DBL / 128;
+  static constexpr int SLOT = REC_DBL + U_DBL + X_DBL;
+  static constexpr int LPB = NREC + NU + NX;           // DMA instructions per block
+  static_assert(REC_DBL % 128 == 0 && U_DBL % 128 == 0, "blocks must be whole DMA instructions");
 };
+
+#ifdef OCS_PL_STAMPS
+#define PL_T() __builtin_amdgcn_s_memtime()
+#else
+#define PL_T() 0LL
+#endif
 
 struct FwdArgsPL {
   int N, batch;
@@ -94,24 +114,25 @@ struct FwdArgsPL {
   const double* u;
   double* x;
   double* J;
+  long long* dbg;  // diagnostic build (-DOCS_PL_STAMPS) only: per-workgroup cycle sums; nullptr otherwise
 };
 
-// Schedule.  nb = N / D blocks.  barrier_k (k = 0..nb) separates interval k-1 from interval k and
-// is reached by M only once block k has landed in LDS.  In interval k
+// ---------------------------------------------------------------------------------------
+// forward.  nb = N / D blocks.  barrier_k (k = 0..nb) separates interval k-1 from interval k and is
+// reached by M only once block k has landed in LDS.  In interval k
 //   M issues the DMA of block k+Q into input slot (k+Q) % NSLOT, then waits for block k+1;
 //   S processes block k     (inputs: slot k % NSLOT;        writes stage buffer k & 1);
 //   C processes block k-1   (inputs: slot (k-1) % NSLOT;    reads stage buffer (k-1) & 1).
 // The slot M overwrites in interval k last served block k+Q-NSLOT = k-2, read by C in interval k-1.
+// ---------------------------------------------------------------------------------------
 template <class P, bool OUT_X>
 __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
   constexpr int G = P::NS, NAUG = P::NAUG;
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
-  using C_ = PLCfg<G>;
-  constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT;
-  constexpr int SLOT = C_::REC_DBL + C_::U_DBL;
-  constexpr int LPB = 1 + C_::NU;  // DMA instructions per block
-  __shared__ __attribute__((aligned(16))) double stage[2][4][D][64];  // [buffer][Y1..Y4][step][lane]
-  __shared__ __attribute__((aligned(16))) double inp[NSLOT][SLOT];    // [slot]{records | u}
+  using C_ = PLCfg<G, false>;
+  constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
+  __shared__ __attribute__((aligned(16))) double stage[2][4][D][64];    // [buffer][Y1..Y4][step][lane]
+  __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];  // [slot]{records | u}
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)a.batch;
@@ -120,26 +141,41 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
 
   if (wave == 0) {
     // ---------------- M: HBM -> LDS ----------------
-    const double* recsrc = a.REC + 2 * lane;                       // records of block j start at REC + j*REC_DBL
-    const int e0 = 2 * lane;                                       // element pair handled by this lane
     auto issue = [&](int j) OCS_INLINE {
       double* dst = &inp[j % NSLOT][0];
-      if (2 * lane < C_::REC_DBL) dma16(recsrc + (size_t)j * C_::REC_DBL, dst);
+#pragma unroll
+      for (int q = 0; q < C_::NREC; ++q)
+        dma16(a.REC + (size_t)j * C_::REC_DBL + q * 128 + 2 * lane, dst + q * 128);
 #pragma unroll
       for (int q = 0; q < C_::NU; ++q) {
-        const int e = q * 128 + e0, row = e / TPW, tl = e % TPW;
+        const int e = q * 128 + 2 * lane, row = e / TPW, tl = e % TPW;
         dma16(a.u + ((size_t)(2 * D * j + 1 + row)) * B + bw + tl, dst + C_::REC_DBL + q * 128);
       }
     };
     for (int j = 0; j < Q && j < nb; ++j) issue(j);
+    long long tw = 0, tb = 0;
+    const long long t00 = PL_T();
     for (int k = 0; k <= nb; ++k) {
+      const long long t0 = PL_T();
       if (k < nb) {
         const int behind = (nb - 1 - k) < (Q - 1) ? (nb - 1 - k) : (Q - 1);  // younger blocks in flight
-        wait_blocks<LPB>(behind);
+        wait_blocks<C_::LPB>(behind);
       }
+      const long long t1 = PL_T();
       lds_barrier();
+      const long long t2 = PL_T();
+      tw += t1 - t0;
+      tb += t2 - t1;
       if (k + Q < nb) issue(k + Q);
     }
+#ifdef OCS_PL_STAMPS
+    if (a.dbg && lane == 0) {
+      a.dbg[blockIdx.x * 16 + 0] = tw;
+      a.dbg[blockIdx.x * 16 + 1] = tb;
+      a.dbg[blockIdx.x * 16 + 2] = PL_T() - t00;
+    }
+#endif
+    (void)tw; (void)tb; (void)t00;
   } else {
     const int r = lane % G;
     const int tl = lane / G;
@@ -156,8 +192,12 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       double uprev = u0;
       double* xs = a.x + (size_t)r * B + b;
       if (OUT_X) *xs = y;
+      long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
+        const long long t0 = PL_T();
         lds_barrier();
+        const long long t1 = PL_T();
+        tb += t1 - t0;
         if (k < nb) {
           const double* rec = &inp[k % NSLOT][0];
           const double* us = rec + C_::REC_DBL + tl;
@@ -167,9 +207,9 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
           struct In { double h, hh, h6, uM, uB; };
           auto fetch = [&](int s) OCS_INLINE {
             In v;
-            v.h = rec[8 * s];
-            v.hh = rec[8 * s + 1];
-            v.h6 = rec[8 * s + 2];
+            v.h = rec[RS * s];
+            v.hh = rec[RS * s + 1];
+            v.h6 = rec[RS * s + 2];
             v.uM = us[(2 * s) * TPW];
             v.uB = us[(2 * s + 1) * TPW];
             return v;
@@ -199,26 +239,39 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             uprev = c.uB;
           }
         }
+        tc += PL_T() - t1;
       }
+#ifdef OCS_PL_STAMPS
+      if (a.dbg && lane == 0) {
+        a.dbg[blockIdx.x * 16 + 4] = tb;
+        a.dbg[blockIdx.x * 16 + 5] = tc;
+      }
+#endif
+      (void)tb; (void)tc;
     } else {
       // ---------------- C: objective ----------------
+      // pc += W_A q1 + W_M (q2 + q3) + W_B q4 with the quadrature weights of the record table
+      // (W_A = h/6 e^{-r t_A}, ...): the same sum as h/6 (F1 + 2 F2 + 2 F3 + F4) of the cost row.
       double pc = 0.0, uprev2 = u0 * u0;
       double* xc = a.x + (size_t)G * B + b;
       if (OUT_X) *xc = 0.0;
+      long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
+        const long long t0 = PL_T();
         lds_barrier();
+        const long long t1 = PL_T();
+        tb += t1 - t0;
         if (k >= 1) {
           const int j = k - 1;
           const double* rec = &inp[j % NSLOT][0];
           const double* us = rec + C_::REC_DBL + tl;
           const double* w = &stage[j & 1][0][0][lane];
-          struct In { double h6, tcA, tcM, tcB, uM, uB, Y1, Y2, Y3, Y4; };
+          struct In { double wA, wM, wB, uM, uB, Y1, Y2, Y3, Y4; };
           auto fetch = [&](int s) OCS_INLINE {
             In v;
-            v.h6 = rec[8 * s + 2];
-            v.tcA = rec[8 * s + 4];
-            v.tcM = rec[8 * s + 5];
-            v.tcB = rec[8 * s + 6];
+            v.wA = rec[RS * s + SCO + 3];
+            v.wM = rec[RS * s + SCO + 4];
+            v.wB = rec[RS * s + SCO + 5];
             v.uM = us[(2 * s) * TPW];
             v.uB = us[(2 * s + 1) * TPW];
             v.Y1 = w[s * 64];
@@ -234,11 +287,9 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             if (s + 1 < D) nxt = fetch(s + 1);
             __builtin_amdgcn_sched_barrier(0);
             const double uM2 = c.uM * c.uM, uB2 = c.uB * c.uB;
-            const double q1 = c.tcA * P::row_q(c.Y1, uprev2, rp);
-            const double q2 = c.tcM * P::row_q(c.Y2, uM2, rp);
-            const double q3 = c.tcM * P::row_q(c.Y3, uM2, rp);
-            const double q4 = c.tcB * P::row_q(c.Y4, uB2, rp);
-            pc = __builtin_fma(c.h6, __builtin_fma(2.0, q3, __builtin_fma(2.0, q2, q1)) + q4, pc);
+            const double q1 = P::row_q(c.Y1, uprev2, rp), q2 = P::row_q(c.Y2, uM2, rp);
+            const double q3 = P::row_q(c.Y3, uM2, rp), q4 = P::row_q(c.Y4, uB2, rp);
+            pc = __builtin_fma(c.wA, q1, __builtin_fma(c.wM, q2 + q3, __builtin_fma(c.wB, q4, pc)));
             if (OUT_X) {
               xc += colB;
               *xc = group_sum_pl<G>(pc);
@@ -246,18 +297,304 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             uprev2 = uB2;
           }
         }
+        tc += PL_T() - t1;
       }
+#ifdef OCS_PL_STAMPS
+      if (a.dbg && lane == 0) {
+        a.dbg[blockIdx.x * 16 + 8] = tb;
+        a.dbg[blockIdx.x * 16 + 9] = tc;
+      }
+#endif
+      (void)tb; (void)tc;
       a.J[b] = group_sum_pl<G>(pc);
     }
   }
 }
 
 // ---------------------------------------------------------------------------------------
+// backward.  Blocks are numbered from the END of the horizon: block j covers steps
+// i = N-1-j*D-s, s = 0..D-1 (the order they are processed in).  barrier_k, k = 0..nb+1.  In interval k
+//   M issues the DMA of block k+Q, then waits for block k+1;
+//   R processes block k     (slot k % NSLOT: checkpoints, controls, records; writes RA[k & 1]);
+//   A processes block k-1   (records of slot (k-1) % NSLOT; reads RA[(k-1) & 1]; writes AD[(k-1) & 1]);
+//   D processes block k-2   (controls, records of slot (k-2) % NSLOT; reads AD[(k-2) & 1]).
+// The slot M overwrites in interval k last served block k+Q-NSLOT = k-3, read by D in interval k-1.
+// ---------------------------------------------------------------------------------------
+struct BwdArgsPL {
+  int N, batch;
+  const double* REC;
+  const double* ps;
+  const double* pb;
+  unsigned pmask;
+  const double* xck;
+  const double* u;
+  const double* lamT;
+  double* lam;   // state rows only; the constant cost row is written by k_fill_lam_cost_row
+  double* dJdu;
+  double* lam0;
+  long long* dbg;  // diagnostic build only
+};
+
+template <class P, bool OUT_LAM, bool OUT_DJDU>
+__global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
+  constexpr int G = P::NS, NAUG = P::NAUG;
+  static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
+  static_assert(G >= 2, "the backward pipeline needs the LDS of a CU for G >= 2 (see DESIGN.md)");
+  using C_ = PLCfg<G, true>;
+  constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
+  constexpr int UOFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::U_DBL;
+  __shared__ __attribute__((aligned(16))) double ra[2][3][D][64];      // R -> A: Y2, Y3, Y4 (Y1 = x_i is in the input slot)
+  __shared__ __attribute__((aligned(16))) double ad[2][3][D][64];      // A -> D: k1, k2 + k3, k4
+  __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT]; // {records | u | checkpoints}
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const size_t B = (size_t)a.batch;
+  const int N = a.N, nb = N / D;
+  const int bw = blockIdx.x * TPW;
+
+  if (wave == 0) {
+    // ---------------- M: HBM -> LDS ----------------
+    auto issue = [&](int j) OCS_INLINE {
+      double* dst = &inp[j % NSLOT][0];
+      const int iLo = N - (j + 1) * D;  // lowest step of the block; LDS holds ascending steps
+#pragma unroll
+      for (int q = 0; q < C_::NREC; ++q)
+        dma16(a.REC + (size_t)iLo * RS + q * 128 + 2 * lane, dst + q * 128);
+#pragma unroll
+      for (int q = 0; q < C_::NU; ++q) {  // samples 2*iLo .. 2*iLo + 2D - 1
+        const int e = q * 128 + 2 * lane, row = e / TPW, tl = e % TPW;
+        dma16(a.u + ((size_t)(2 * iLo + row)) * B + bw + tl, dst + UOFF + q * 128);
+      }
+#pragma unroll
+      for (int q = 0; q < C_::NX; ++q) {  // checkpoint rows x(r, i), LDS layout [step][r][tl]
+        const int e = q * 128 + 2 * lane, st = e / 64, rr = (e % 64) / TPW, tl = e % TPW;
+        dma16(a.xck + ((size_t)(iLo + st) * NAUG + rr) * B + bw + tl, dst + XOFF + q * 128);
+      }
+    };
+    for (int j = 0; j < Q && j < nb; ++j) issue(j);
+    for (int k = 0; k <= nb + 1; ++k) {
+      if (k < nb) {
+        const int behind = (nb - 1 - k) < (Q - 1) ? (nb - 1 - k) : (Q - 1);
+        wait_blocks<C_::LPB>(behind);
+      }
+      lds_barrier();
+      if (k + Q < nb) issue(k + Q);
+    }
+    return;
+  }
+  const int r = lane % G;
+  const int tl = lane / G;
+  const int b = bw + tl;
+  const uniform_ptr PS = as_uniform(a.ps);
+  const typename P::RowPar rp = P::load_row([&](int k) OCS_INLINE {
+    return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+  }, r);
+  const double lamc = a.lamT ? a.lamT[(size_t)G * B + b] : 1.0;
+  const size_t colB = (size_t)NAUG * B;
+
+  if (wave == 1) {
+    // ---------------- R: stage states and the affine coefficients of the adjoint rows ----------------
+    long long tb = 0, tc = 0;
+    for (int k = 0; k <= nb + 1; ++k) {
+      const long long t0 = PL_T();
+      lds_barrier();
+      const long long t1 = PL_T();
+      tb += t1 - t0;
+      if (k < nb) {
+        const double* slot = &inp[k % NSLOT][0];
+        const double* us = slot + UOFF + tl;
+        const double* xs = slot + XOFF + r * TPW + tl;
+        double* w = &ra[k & 1][0][0][lane];
+        struct In { double h, hh, xi, uA, uM; };
+        auto fetch = [&](int s) OCS_INLINE {  // s-th step processed = local ascending index D-1-s
+          const int l = D - 1 - s;
+          In v;
+          v.h = slot[RS * l];
+          v.hh = slot[RS * l + 1];
+          v.xi = xs[l * 64];
+          v.uA = us[(2 * l) * TPW];
+          v.uM = us[(2 * l + 1) * TPW];
+          return v;
+        };
+        In nxt = fetch(0);
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          const In c = nxt;
+          if (s + 1 < D) nxt = fetch(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          double f = P::row_f(c.xi, c.uA, rp);
+          const double Y2 = __builtin_fma(c.hh, f, c.xi);
+          f = P::row_f(Y2, c.uM, rp);
+          const double Y3 = __builtin_fma(c.hh, f, c.xi);
+          f = P::row_f(Y3, c.uM, rp);
+          const double Y4 = __builtin_fma(c.h, f, c.xi);
+          w[(0 * D + s) * 64] = Y2;
+          w[(1 * D + s) * 64] = Y3;
+          w[(2 * D + s) * 64] = Y4;
+        }
+      }
+      tc += PL_T() - t1;
+    }
+#ifdef OCS_PL_STAMPS
+    if (a.dbg && lane == 0) {
+      a.dbg[blockIdx.x * 16 + 0] = tb;
+      a.dbg[blockIdx.x * 16 + 1] = tc;
+    }
+#endif
+    (void)tb; (void)tc;
+  } else if (wave == 2) {
+    // ---------------- A: adjoint recursion ----------------
+    double lam = a.lamT ? a.lamT[(size_t)r * B + b] : 0.0;
+    double* ls = a.lam + (size_t)N * colB + (size_t)r * B + b;
+    if (OUT_LAM) *ls = lam;
+    long long tb = 0, tc = 0;
+    for (int k = 0; k <= nb + 1; ++k) {
+      const long long t0 = PL_T();
+      lds_barrier();
+      const long long t1 = PL_T();
+      tb += t1 - t0;
+      if (k >= 1 && k <= nb) {
+        const int j = k - 1;
+        const double* slot = &inp[j % NSLOT][0];
+        const double* w = &ra[j & 1][0][0][lane];
+        double* kw = &ad[j & 1][0][0][lane];
+        const double* xs = slot + XOFF + r * TPW + tl;
+        struct In { double h, hh, h6, h3, e4, e3, e1, Y1, Y2, Y3, Y4; };
+        auto fetch = [&](int s) OCS_INLINE {
+          const int l = D - 1 - s;
+          In v;
+          v.h = slot[RS * l];
+          v.hh = slot[RS * l + 1];
+          v.h6 = slot[RS * l + 2];
+          v.h3 = slot[RS * l + 3];
+          v.e4 = slot[RS * l + SCO];
+          v.e3 = slot[RS * l + SCO + 1];
+          v.e1 = slot[RS * l + SCO + 2];
+          v.Y1 = xs[l * 64];
+          v.Y2 = w[(0 * D + s) * 64];
+          v.Y3 = w[(1 * D + s) * 64];
+          v.Y4 = w[(2 * D + s) * 64];
+          return v;
+        };
+        In nxt = fetch(0);
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          const In c = nxt;
+          if (s + 1 < D) nxt = fetch(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const double ev4 = c.e4 * lamc, ev3 = c.e3 * lamc, ev1 = c.e1 * lamc;
+          const double h6l = c.h6 * lam, h3l = c.h3 * lam;
+          const double k4 = h6l;                                   // :73
+          const double g3 = P::row_dfdx(c.Y4, k4, ev4, rp);        // :74-75
+          const double k3 = __builtin_fma(c.h, g3, h3l);           // :77
+          const double g2 = P::row_dfdx(c.Y3, k3, ev3, rp);        // :78-79
+          const double k2 = __builtin_fma(c.hh, g2, h3l);          // :81
+          const double g1 = P::row_dfdx(c.Y2, k2, ev3, rp);        // :82-83
+          const double k1 = __builtin_fma(c.hh, g1, h6l);          // :85
+          const double g0 = P::row_dfdx(c.Y1, k1, ev1, rp);        // :87-88
+          lam = (((lam + g1) + g2) + g3) + g0;                     // :86-88
+          if (OUT_DJDU) {
+            kw[(0 * D + s) * 64] = k1;
+            kw[(1 * D + s) * 64] = k2 + k3;
+            kw[(2 * D + s) * 64] = k4;
+          }
+          if (OUT_LAM) {
+            ls -= colB;
+            *ls = lam;
+          }
+        }
+      }
+      tc += PL_T() - t1;
+    }
+#ifdef OCS_PL_STAMPS
+    if (a.dbg && lane == 0) {
+      a.dbg[blockIdx.x * 16 + 4] = tb;
+      a.dbg[blockIdx.x * 16 + 5] = tc;
+    }
+#endif
+    (void)tb; (void)tc;
+    if (a.lam0) {
+      a.lam0[(size_t)r * B + b] = lam;
+      a.lam0[(size_t)G * B + b] = lamc;
+    }
+  } else {
+    // ---------------- D: dJdu columns ----------------
+    double* dp = a.dJdu + (size_t)(2 * N) * B + b;  // dJdu(2N+1), walks down
+    double cunext = rp.cw * a.u[(size_t)(2 * N) * B + b], pend = 0.0;
+    long long tb = 0, tc = 0;
+    for (int k = 0; k <= nb + 1; ++k) {
+      const long long t0 = PL_T();
+      lds_barrier();
+      const long long t1 = PL_T();
+      tb += t1 - t0;
+      if (OUT_DJDU && k >= 2) {
+        const int j = k - 2;
+        const double* slot = &inp[j % NSLOT][0];
+        const double* us = slot + UOFF + tl;
+        const double* kw = &ad[j & 1][0][0][lane];
+        struct In { double e4, e3, e1, uA, uM, k1, k23, k4; };
+        auto fetch = [&](int s) OCS_INLINE {
+          const int l = D - 1 - s;
+          In v;
+          v.e4 = slot[RS * l + SCO];
+          v.e3 = slot[RS * l + SCO + 1];
+          v.e1 = slot[RS * l + SCO + 2];
+          v.uA = us[(2 * l) * TPW];
+          v.uM = us[(2 * l + 1) * TPW];
+          v.k1 = kw[(0 * D + s) * 64];
+          v.k23 = kw[(1 * D + s) * 64];
+          v.k4 = kw[(2 * D + s) * 64];
+          return v;
+        };
+        In nxt = fetch(0);
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          const In c = nxt;
+          if (s + 1 < D) nxt = fetch(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const double ev4 = c.e4 * lamc, ev3 = c.e3 * lamc, ev1 = c.e1 * lamc;
+          const double cuA = rp.cw * c.uA, cuM = rp.cw * c.uM;
+          const double p4 = P::row_dfdu(cunext, c.k4, ev4), p1 = P::row_dfdu(cuA, c.k1, ev1);
+          // p2 + p3 = (cuM ev3 - k2) + (cuM ev3 - k3) = 2 cuM ev3 - (k2 + k3)
+          const double p23 = __builtin_fma(cuM + cuM, ev3, -c.k23);
+          *dp = group_sum_pl<G>(pend + p4);   // column 2i+2
+          dp -= B;
+          *dp = group_sum_pl<G>(p23);         // column 2i+1
+          dp -= B;
+          pend = p1;
+          cunext = cuA;
+        }
+      }
+      tc += PL_T() - t1;
+    }
+#ifdef OCS_PL_STAMPS
+    if (a.dbg && lane == 0) {
+      a.dbg[blockIdx.x * 16 + 8] = tb;
+      a.dbg[blockIdx.x * 16 + 9] = tc;
+    }
+#endif
+    (void)tb; (void)tc;
+    if (OUT_DJDU) *dp = group_sum_pl<G>(pend);  // left end point :101-102
+  }
+}
+
+// lam(end, :) is constant along a trajectory (the last row of dFdx_times_vec is zero): one streaming fill
+__global__ void k_fill_lam_cost_row(int N, int nAug, int batch, const double* __restrict__ lamT,
+                                    double* __restrict__ lam) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int i = blockIdx.y;
+  if (b >= batch || i > N) return;
+  const double v = lamT ? lamT[(size_t)(nAug - 1) * batch + b] : 1.0;
+  lam[((size_t)i * nAug + (nAug - 1)) * batch + b] = v;
+}
+
+// ---------------------------------------------------------------------------------------
 bool pipeline_supported(Functor f, int nS, int nC) {
   return f == Functor::Logistic && (nS == 1 || nS == 2 || nS == 4) && nC == 1;
 }
-bool pipeline_shape_ok(int nS, int N, int batch) {
-  const int D = (nS == 4) ? 16 : 8, TPW = 64 / nS;
+bool pipeline_shape_ok(int nS, int N, int batch, bool backward) {
+  if (backward && nS < 2) return false;
+  const int D = (!backward && nS == 4) ? 16 : 8, TPW = 64 / nS;
   return N >= D && N % D == 0 && batch % TPW == 0;
 }
 
@@ -272,8 +609,15 @@ static void run_forward_pl(const FwdArgsPL& a, hipStream_t s) {
 }
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, hipStream_t s) {
-  if (!pipeline_shape_ok(p.nS, g.N, batch)) return -1;
-  const FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J};
+  if (!pipeline_shape_ok(p.nS, g.N, batch, false)) return -1;
+  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr};
+#ifdef OCS_PL_STAMPS
+  static long long* dbg = nullptr;
+  const int nwg = batch / (64 / p.nS);
+  if (!dbg) (void)hipMalloc((void**)&dbg, sizeof(long long) * 16 * 65536);
+  (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 16 * nwg, s);
+  a.dbg = dbg;
+#endif
   if (p.nS == 1)
     run_forward_pl<LogisticK<1>>(a, s);
   else if (p.nS == 2)
@@ -282,6 +626,69 @@ int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const 
     run_forward_pl<LogisticK<4>>(a, s);
   else
     return -1;
+#ifdef OCS_PL_STAMPS
+  {
+    (void)hipStreamSynchronize(s);
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      std::vector<long long> h(16 * nwg);
+      (void)hipMemcpy(h.data(), dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+      double acc[16] = {0};
+      for (int w = 0; w < nwg; ++w)
+        for (int q = 0; q < 16; ++q) acc[q] += (double)h[16 * w + q] / nwg;
+      fprintf(stderr, "[pl fwd nS=%d] cycles per wg: M wait %.0f barrier %.0f total %.0f | S barrier %.0f compute %.0f | C barrier %.0f compute %.0f\n",
+              p.nS, acc[0], acc[1], acc[2], acc[4], acc[5], acc[8], acc[9]);
+    }
+  }
+#endif
+  return hip_rc5(hipGetLastError());
+}
+
+template <class P>
+static void run_backward_pl(const BwdArgsPL& a, hipStream_t s) {
+  constexpr int TPW = 64 / P::NS;
+  const dim3 grid(a.batch / TPW), block(256);
+  if (a.lam && a.dJdu)
+    k_backward_pl<P, true, true><<<grid, block, 0, s>>>(a);
+  else if (a.lam)
+    k_backward_pl<P, true, false><<<grid, block, 0, s>>>(a);
+  else
+    k_backward_pl<P, false, true><<<grid, block, 0, s>>>(a);
+}
+int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                       const double* lamT, double* lam, double* dJdu, double* lam0, hipStream_t s) {
+  if (!pipeline_shape_ok(p.nS, g.N, batch, true) || (!lam && !dJdu)) return -1;
+  BwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, lam0, nullptr};
+#ifdef OCS_PL_STAMPS
+  static long long* dbgb = nullptr;
+  const int nwg = batch / (64 / p.nS);
+  if (!dbgb) (void)hipMalloc((void**)&dbgb, sizeof(long long) * 16 * 65536);
+  (void)hipMemsetAsync(dbgb, 0, sizeof(long long) * 16 * nwg, s);
+  a.dbg = dbgb;
+#endif
+  if (lam)
+    k_fill_lam_cost_row<<<dim3((batch + 255) / 256, g.N + 1), dim3(256), 0, s>>>(g.N, p.nS + 1, batch, lamT, lam);
+  if (p.nS == 2)
+    run_backward_pl<LogisticK<2>>(a, s);
+  else if (p.nS == 4)
+    run_backward_pl<LogisticK<4>>(a, s);
+  else
+    return -1;
+#ifdef OCS_PL_STAMPS
+  {
+    (void)hipStreamSynchronize(s);
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      std::vector<long long> h(16 * nwg);
+      (void)hipMemcpy(h.data(), dbgb, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+      double acc[16] = {0};
+      for (int w = 0; w < nwg; ++w)
+        for (int q = 0; q < 16; ++q) acc[q] += (double)h[16 * w + q] / nwg;
+      fprintf(stderr, "[pl bwd nS=%d] cycles per wg: R barrier %.0f compute %.0f | A barrier %.0f compute %.0f | D barrier %.0f compute %.0f\n",
+              p.nS, acc[0], acc[1], acc[4], acc[5], acc[8], acc[9]);
+    }
+  }
+#endif
   return hip_rc5(hipGetLastError());
 }
 

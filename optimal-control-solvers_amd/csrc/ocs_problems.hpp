@@ -83,6 +83,19 @@ struct LogisticK {
     for (int k = 1; k < NS; ++k) s -= v[k];
     g[0] = __builtin_fma(2.0 * p.c * tc[0] * u[0], v[NS], s);
   }
+  // Per-step constants that depend on the grid only (uniform over the batch); computed once into the
+  // record table so that the wave-specialised kernels need not recompute them per lane and step.
+  static constexpr int NSC = 6;
+  __device__ static inline void step_consts(double h6, double h3, const double* tcA, const double* tcM,
+                                            const double* tcB, double* sc) {
+    sc[0] = (2.0 * tcB[0]) * h6;  // E4:  2 e^{-r t} * (h/6): cost-row factor of dFdx_times_vec at stage 4
+    sc[1] = (2.0 * tcM[0]) * h3;  // E3 (= E2)
+    sc[2] = (2.0 * tcA[0]) * h6;  // E1
+    sc[3] = h6 * tcA[0];          // W_A: RK4 quadrature weights of the objective integrand
+    sc[4] = 2.0 * (h6 * tcM[0]);  // W_M
+    sc[5] = h6 * tcB[0];          // W_B
+  }
+
   // ---- row-separable form (row-split mapping, ocs_rowsplit_kernels.hip) --------------------
   // Row k of F depends on y_k and u only, and the objective integrand is a sum of per-row terms
   // q_k(y_k, u) (the control cost c u^2 is charged to row 0), so a group of NS lanes can own one
@@ -112,6 +125,12 @@ struct LogisticK {
   // row r of (dF/dy)' v:  (m_r - 2 y) v_r + ev y,   ev = 2 e^{-rt} v_cost
   __device__ static inline double row_dfdx(double y, double v, double ev, const RowPar& rp) {
     return __builtin_fma(__builtin_fma(-2.0, y, rp.m), v, ev * y);
+  }
+  // the same row in affine form g = a v_r + b (a, b do not depend on v_r, so a wave that runs ahead of
+  // the adjoint recursion can prepare them):  a = m_r - 2 y,  b = ev y
+  __device__ static inline void row_dfdx_pre(double y, double ev, const RowPar& rp, double& a, double& b) {
+    a = __builtin_fma(-2.0, y, rp.m);
+    b = ev * y;
   }
   // this row's share of (dF/du)' v:  -v_r + cw u ev,   cu = cw u
   __device__ static inline double row_dfdu(double cu, double v, double ev) {
