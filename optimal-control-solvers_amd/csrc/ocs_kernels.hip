@@ -621,24 +621,37 @@ static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
   else
     k_forward<P, kChunk, pf_of<P>(), false, false><<<grid, block, 0, s>>>(a);
 }
-// Row-split pays while the lane-per-trajectory kernel would leave most SIMDs idle (fewer waves than
-// SIMDs); beyond that the lane mapping has the lower instruction count per trajectory and the lower
-// register pressure, and the passes turn HBM-bound anyway.
-static bool use_rowsplit(const ProblemDesc& p, int batch, int mapping, bool plain) {
-  if (!plain || mapping == MAP_LANE || !rowsplit_supported(p.functor, p.nS, p.nC)) return false;
-  if (mapping == MAP_ROWSPLIT) return true;
-  return batch <= 8192;
+// Mapping selection (measured on MI355X, Logistic4, N = 1008; pass pair in us):
+//   batch      lane   row-split   pipeline
+//    1024       644       322        230
+//    4096       672       363        238
+//    8192       731       520        446
+//   16384       821       960        860
+// The wave-specialised pipeline wins while its workgroups (one per 64/nS trajectories, most of a CU's
+// LDS each) fit on the chip in at most two rounds; row-split while the lane mapping would leave most
+// SIMDs idle; beyond that the lane mapping has the fewest instructions per trajectory and the
+// passes turn HBM-bound anyway.
+static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested, bool plain, bool backward) {
+  if (requested != MAP_AUTO) return requested;
+  if (plain && pipeline_supported(p.functor, p.nS, p.nC) && pipeline_shape_ok(p.nS, N, batch, backward) &&
+      batch / (64 / p.nS) <= 512)
+    return MAP_PIPELINE;
+  if (plain && rowsplit_supported(p.functor, p.nS, p.nC) && batch <= 8192) return MAP_ROWSPLIT;
+  return MAP_LANE;
 }
 
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
-  if (o.mapping == MAP_PIPELINE) {
-    if (o.uconst || o.Jadd || o.usel || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
+  const bool plain = !o.uconst && !o.Jadd && !o.usel;
+  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, false);
+  if (map == MAP_PIPELINE) {
+    if (!plain || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
     return launch_forward_pl(p, g, batch, x0, u, x, J, s);
   }
-  if (use_rowsplit(p, batch, o.mapping, !o.uconst && !o.Jadd && !o.usel))
+  if (map == MAP_ROWSPLIT) {
+    if (!plain || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;
     return launch_forward_rs(p, g, batch, x0, u, x, J, s);
-  if (o.mapping == MAP_ROWSPLIT) return -1;
+  }
   if (o.uconst && !x) return -1;
   const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.usel, o.udelta};
   OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, o.uconst, s));
@@ -659,13 +672,16 @@ static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
 }
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
-  if (o.mapping == MAP_PIPELINE) {
-    if (o.uconst || o.usel || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
+  const bool plain = !o.uconst && !o.usel;
+  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, true);
+  if (map == MAP_PIPELINE) {
+    if (!plain || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
     return launch_backward_pl(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
   }
-  if (use_rowsplit(p, batch, o.mapping, !o.uconst && !o.usel))
+  if (map == MAP_ROWSPLIT) {
+    if (!plain || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;
     return launch_backward_rs(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
-  if (o.mapping == MAP_ROWSPLIT) return -1;
+  }
   if (o.uconst ? (lam || dJdu || !o.lam0) : (!lam && !dJdu)) return -1;
   const BwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, o.lam0, o.usel, o.udelta};
   OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, o.uconst, s));

@@ -80,7 +80,7 @@ __device__ static inline void wait_blocks(int blocks) {
 
 template <int G, bool BWD>
 struct PLCfg {
-  static constexpr int D = (!BWD && G == 4) ? 16 : 8;  // steps per hand-off block
+  static constexpr int D = 8;                          // steps per hand-off block (BASELINE N = 1000 = 125 blocks)
   static constexpr int TPW = 64 / G;                   // trajectories per workgroup
   static constexpr int Q = 3;                          // blocks the memory wave runs ahead (wait_blocks: <= 2 younger)
   static constexpr int LAG = BWD ? 2 : 1;              // intervals between the first and the last reader of a slot
@@ -594,7 +594,8 @@ bool pipeline_supported(Functor f, int nS, int nC) {
 }
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward) {
   if (backward && nS < 2) return false;
-  const int D = (!backward && nS == 4) ? 16 : 8, TPW = 64 / nS;
+  const int D = 8, TPW = 64 / nS;
+  (void)backward;
   return N >= D && N % D == 0 && batch % TPW == 0;
 }
 

@@ -99,7 +99,7 @@ def test_both_mappings_match_oracle(ocs, oracle, nS, N, batch, T, mapping):
     tspan, x0, u = _inputs(oracle, nS, N, batch, seed=300 + nS + N, T=T)
     pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
     g = ocs.RK4Integrator(tspan).set_mapping(mapping)
-    D, tile = (16 if nS == 4 else 8), 64 // nS
+    D, tile = 8, 64 // nS
     if mapping == "pipeline" and (N % D != 0 or batch % tile != 0):
         # the wave-specialised kernels hand off in blocks of D steps over tiles of 64/nS trajectories:
         # other shapes are refused when forced (automatic selection falls back), never mis-computed
