@@ -216,8 +216,9 @@ def main():
                                    f"batch={batch} control candidates per GPU, full output (x,J,lam,dJdu)",
                        "problem": "LogisticK(m=[3,2.5,2,1.5], c=1.5, r=0.05)", "n_steps": NSTEPS,
                        "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}",
-                       "mapping": "lane-per-trajectory"},
-            "roofline": {"bound": "hbm", "kernel": "k_backward (compute_adjoints + compute_dJdu)",
+                       "mapping": "automatic (batch <= 8192: wave-specialised pipeline, one state row per lane)"},
+            "roofline": {"bound": "hbm", "kernel": "k_backward_pl (compute_adjoints + compute_dJdu; at this batch the "
+                                                   "wave-specialised kernel, plus its 3 us cost-row fill)",
                          "achieved": bytes_bwd / t_bwd / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": bytes_bwd / t_bwd / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_s": t_bwd},

@@ -17,14 +17,14 @@ struct ocs_fbs_state {
   unsigned long long tu_version = 0;
   const ocs_problem_s* tu_prob = nullptr;
   // work arrays
-  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage;
+  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid;
 };
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
   if (!s) return;
   DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
                     &s->TI, &s->TUI, &s->xaug, &s->xmid, &s->lam, &s->lmid, &s->ugrid, &s->uerr, &s->uint_, &s->J,
-                    &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage};
+                    &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage, &s->metric, &s->anyvalid};
   for (DevBuf* b : bufs) b->release();
   delete s;
 }
@@ -187,10 +187,14 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const size_t ugridN = (size_t)nT * nC * B, uerrN = (size_t)nE * nC * B;
   OCS_TRY(f->xmid.ensure(sizeof(double) * (size_t)N * nS * B));
   OCS_TRY(f->lmid.ensure(sizeof(double) * (size_t)N * nS * B));
-  OCS_TRY(f->ugrid.ensure(sizeof(double) * 2 * ugridN));
+  OCS_TRY(f->ugrid.ensure(sizeof(double) * ugridN));
   OCS_TRY(f->uerr.ensure(sizeof(double) * 2 * uerrN));
   OCS_TRY(f->usel.ensure(sizeof(int) * B));
   OCS_TRY(f->nactive.ensure(sizeof(int)));
+  OCS_TRY(f->metric.ensure(sizeof(unsigned long long) * B));
+  OCS_TRY(f->anyvalid.ensure(sizeof(int) * B));
+  HIP_TRY(hipMemsetAsync(f->metric.p, 0, sizeof(unsigned long long) * B, s));
+  HIP_TRY(hipMemsetAsync(f->anyvalid.p, 0, sizeof(int) * B, s));
   double* mc = maxChange;
   if (!mc) {
     OCS_TRY(f->maxchange.ensure(sizeof(double) * (size_t)opt->nSWEEPS * B));
@@ -210,25 +214,25 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const ProblemDesc pd = describe(p);
   const GridDesc gd = describe(g);
   const FbsTables tb = tabs(g);
-  const int* usel = (const int*)f->usel.p;
-  FwdOpts fo;
-  fo.usel = usel;
-  fo.udelta = (long long)ugridN;
+  const int* usel = (const int*)f->usel.p;  // selects the old / new buffer of the ERROR-POINT samples only
   int nactive = batch;
   for (int sweep = 1; sweep <= opt->nSWEEPS && nactive > 0; ++sweep) {  // :79
-    // uNew = sweep(u): compute_x_lam (:95) then uNew = ControlChar(t, x(t), lam(t)) (:96)
-    LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
+    // uNew = sweep(u): compute_x_lam (:95) ...
+    LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, FwdOpts(), s));
     LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
-    LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), usel, (long long)ugridN, lam, s));
-    LAUNCH_TRY(launch_pchip_mid(tb, nS, nS, batch, lam, f->lmid.d(), s));
-    LAUNCH_TRY(launch_control_grid(pd, gd, batch, xaug, nAug, f->xmid.d(), lam, f->lmid.d(), f->ugrid.d(), usel,
-                                   (long long)ugridN, s));
-    LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
-                                  f->uerr.d(), usel, (long long)uerrN, s));
-    // check_convergence(uNew, u)  :81, :99-115
+    LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), nullptr, 0, lam, s));
+    // ... uNew = ControlChar(t, x(t), lam(t)) (:96) on the error points, with check_convergence(uNew, u)
+    // (:81, :99-115) folded in
     HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));
-    LAUNCH_TRY(launch_fbs_advance(batch, nE, nC, sweep, opt->uRelTol, opt->uAbsTol, f->uerr.d(), (long long)uerrN,
+    LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
+                                  f->uerr.d(), usel, (long long)uerrN, (unsigned long long*)f->metric.p,
+                                  (int*)f->anyvalid.p, opt->uRelTol, opt->uAbsTol, s));
+    LAUNCH_TRY(launch_fbs_advance(batch, sweep, (unsigned long long*)f->metric.p, (int*)f->anyvalid.p,
                                   (int*)f->usel.p, status, mc, (int*)f->nactive.p, s));
+    // u = uNew (:85) on the integrator grid, only for the instances that continue: a converged instance
+    // keeps its OLD control, which is what final_sweep(u) integrates (:82)
+    LAUNCH_TRY(launch_pchip_mid(tb, nS, nS, batch, lam, f->lmid.d(), s));
+    LAUNCH_TRY(launch_control_grid(pd, gd, batch, xaug, nAug, f->xmid.d(), lam, f->lmid.d(), f->ugrid.d(), status, s));
     HIP_TRY(hipMemcpyAsync(&nactive, f->nactive.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }
@@ -236,7 +240,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // (a frozen instance is re-integrated with the same u each later sweep, bit for bit); what is left is
   // uOpt = ControlChar(interpPts, xOpt(interpPts), lamOpt(interpPts))  :123
   LAUNCH_TRY(launch_control_pts(pd, tb, nI, (const int*)f->KI.p, f->SI.d(), f->TUI.d(), batch, xaug, nAug, lam,
-                                uInterp, nullptr, 0, s));
+                                uInterp, nullptr, 0, nullptr, nullptr, 0.0, 0.0, s));
   return nactive > 0 ? OCS_NUM_NOT_CONVERGED : OCS_OK;
 }
 

@@ -157,39 +157,9 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
     rq[q] = load_rec<NTC>(recp);
     recp -= rec_stride(NTC);
   }
-  // node/midpoint samples of step i-1 are requested while step i is computed
-  double xA[NS], xM[NS], uA[NC], uM[NC];
-  auto fetch = [&](int i) OCS_INLINE {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      xA[k] = xp[((size_t)i * a.ldx + k) * B];
-      xM[k] = mp[((size_t)i * NS + k) * B];
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      uA[c] = up[((size_t)(2 * i) * NC + c) * B];
-      uM[c] = up[((size_t)(2 * i + 1) * NC + c) * B];
-    }
-  };
-  fetch(N - 1);
-  for (int i = N - 1; i >= 0; --i) {
-    const Rec r = rq[0];
-#pragma unroll
-    for (int q = 0; q + 1 < PF; ++q) rq[q] = rq[q + 1];
-    rq[PF - 1] = load_rec<NTC>(recp);
-    recp -= rec_stride(NTC);
-    double cxA[NS], cxM[NS], cuA[NC], cuM[NC];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      cxA[k] = xA[k];
-      cxM[k] = xM[k];
-    }
-#pragma unroll
-    for (int c = 0; c < NC; ++c) {
-      cuA[c] = uA[c];
-      cuM[c] = uM[c];
-    }
-    fetch(i > 0 ? i - 1 : 0);
+  // node/midpoint states and control samples are prefetched one chunk (CH steps) ahead, ping-pong
+  auto step = [&](const Rec& r, int i, const double* cxA, const double* cxM, const double* cuA,
+                  const double* cuM) OCS_INLINE {
     // classical RK4 with step -h from node i+1 to node i
     double k1[NS], k2[NS], k3[NS], k4[NS], L[NS];
     rhs(r.tcB, xB, l, uB, k1);
@@ -210,14 +180,75 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) uB[c] = cuA[c];
+  };
+  auto next_rec = [&]() OCS_INLINE {
+    const Rec r = rq[0];
+#pragma unroll
+    for (int q = 0; q + 1 < PF; ++q) rq[q] = rq[q + 1];
+    rq[PF - 1] = load_rec<NTC>(recp);
+    recp -= rec_stride(NTC);
+    return r;
+  };
+  constexpr int CH = 8;
+  const int nch = N / CH;
+  for (int i = N - 1; i >= nch * CH; --i) {  // remainder steps at the top, direct loads
+    double xA[NS], xM[NS], uA[NC], uM[NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      xA[k] = xp[((size_t)i * a.ldx + k) * B];
+      xM[k] = mp[((size_t)i * NS + k) * B];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      uA[c] = up[((size_t)(2 * i) * NC + c) * B];
+      uM[c] = up[((size_t)(2 * i + 1) * NC + c) * B];
+    }
+    const Rec r = next_rec();
+    step(r, i, xA, xM, uA, uM);
   }
+  struct Chunk {
+    double xA[CH][NS], xM[CH][NS], uA[CH][NC], uM[CH][NC];
+  };
+  Chunk c0, c1;
+  auto load_chunk = [&](Chunk& d, int c) OCS_INLINE {
+#pragma unroll
+    for (int s = CH - 1; s >= 0; --s) {
+      const int i = c * CH + s;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        d.xA[s][k] = xp[((size_t)i * a.ldx + k) * B];
+        d.xM[s][k] = mp[((size_t)i * NS + k) * B];
+      }
+#pragma unroll
+      for (int cc = 0; cc < NC; ++cc) {
+        d.uA[s][cc] = up[((size_t)(2 * i) * NC + cc) * B];
+        d.uM[s][cc] = up[((size_t)(2 * i + 1) * NC + cc) * B];
+      }
+    }
+  };
+  auto run_chunk = [&](const Chunk& d, int c) OCS_INLINE {
+#pragma unroll
+    for (int s = CH - 1; s >= 0; --s) {
+      const Rec r = next_rec();
+      step(r, c * CH + s, d.xA[s], d.xM[s], d.uA[s], d.uM[s]);
+    }
+  };
+  int c = nch - 1;
+  if (c >= 0) load_chunk(c0, c);
+  for (; c >= 1; c -= 2) {
+    load_chunk(c1, c - 1);
+    run_chunk(c0, c);
+    if (c >= 2) load_chunk(c0, c - 2);
+    run_chunk(c1, c - 1);
+  }
+  if (c == 0) run_chunk(c0, 0);
   if (warm == 1.234567e300) lp[0] = warm;  // never true; keeps the table sweep alive
 }
 
 // ---------------------------------------------------------------------------------------
 // new control on the grid: uNew(t_j) = ControlChar(t_j, x(t_j), lam(t_j))   fb_sweep.m:96
-// nodes use the node samples, midpoints the pchip midpoints; written to the buffer that is NOT
-// the instance's current one.
+// nodes use the node samples, midpoints the pchip midpoints.  Runs AFTER the convergence decision of
+// the sweep and overwrites u in place for the instances that continue.
 // ---------------------------------------------------------------------------------------
 struct ControlGridArgs {
   int N, batch;
@@ -232,9 +263,9 @@ struct ControlGridArgs {
   const double* xmid;  // [N][nS][B]
   const double* lam;   // [N+1][nS][B]
   const double* lmid;  // [N][nS][B]
-  double* u;           // base of buffer 0; buffer 1 = u + udelta
-  const int* usel;     // current buffer per instance
-  long long udelta;
+  double* u;           // the control grid, updated in place
+  const int* status;   // only instances that are still active (status 0) take the new control (fb_sweep.m:85);
+                       // a converged instance keeps its old one for the final sweep (:82)
 };
 
 template <class P>
@@ -242,7 +273,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;  // grid point
-  if (b >= a.batch) return;
+  if (b >= a.batch || a.status[b] != 0) return;
   const size_t B = (size_t)a.batch;
   const typename P::Par p = P::load([&](int k) OCS_INLINE {
     return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : a.ps[k];
@@ -270,9 +301,8 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
     ub[c] = a.ub[c];
   }
   P::control_char(tu, x, lam, p, lb, ub, u);
-  double* dst = a.u + (long long)(1 - a.usel[b]) * a.udelta;
 #pragma unroll
-  for (int c = 0; c < NC; ++c) dst[((size_t)j * NC + c) * B + b] = u[c];
+  for (int c = 0; c < NC; ++c) a.u[((size_t)j * NC + c) * B + b] = u[c];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -297,14 +327,24 @@ struct ControlPtsArgs {
   double* out;
   const int* usel;
   long long odelta;
+  // error-point mode (usel != nullptr): the weighted change |uNew - u| / (relTol |u| + absTol) against the
+  // instance's current buffer is folded into metric[b] (bit pattern of a non-negative double, atomicMax)
+  unsigned long long* metric;
+  int* anyvalid;
+  double relTol, absTol;
 };
+
+constexpr int kPtsPerThread = 8;
 
 template <class P>
 __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int q = blockIdx.y;
   if (b >= a.batch) return;
+  double wmax = 0.0;
+  bool any = false;
+  const int q0 = (int)blockIdx.y * kPtsPerThread;
+  for (int q = q0; q < q0 + kPtsPerThread && q < a.nq; ++q) {
   const size_t B = (size_t)a.batch;
   const typename P::Par p = P::load([&](int k) OCS_INLINE {
     return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : a.ps[k];
@@ -328,6 +368,23 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   double* dst = a.out + (a.usel ? (long long)(1 - a.usel[b]) * a.odelta : 0);
 #pragma unroll
   for (int c = 0; c < NC; ++c) dst[((size_t)q * NC + c) * B + b] = u[c];
+  if (a.metric) {  // fb_sweep.m:107  abs(uNew - u) ./ (uRelTol*abs(u) + uAbsTol), max() skips NaN (:108)
+    const double* old = a.out + (long long)a.usel[b] * a.odelta;
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      const double o = old[((size_t)q * NC + c) * B + b];
+      const double w = fabs(u[c] - o) / (a.relTol * fabs(o) + a.absTol);
+      if (w == w) {
+        wmax = any ? fmax(wmax, w) : w;
+        any = true;
+      }
+    }
+  }
+  }  // q
+  if (a.metric && any) {
+    atomicMax(&a.metric[b], (unsigned long long)__double_as_longlong(wmax));
+    a.anyvalid[b] = 1;
+  }
 }
 
 // ControlChar-side time coefficients at arbitrary times
@@ -346,32 +403,23 @@ __global__ void k_tu_at(int nq, const double* __restrict__ tq, const double* __r
 // status: 0 active, k > 0 converged at sweep k.  An active instance whose change is <= 1 keeps
 // its OLD control (final_sweep(u), :82) and freezes; otherwise it switches to the new buffer.
 // ---------------------------------------------------------------------------------------
-__global__ void k_fbs_advance(int batch, int nerr, int nC, int sweep, double relTol, double absTol,
-                              const double* __restrict__ uerr, long long edelta, int* __restrict__ usel,
-                              int* __restrict__ status, double* __restrict__ maxChange, int* __restrict__ nactive) {
+__global__ void k_fbs_advance(int batch, int sweep, unsigned long long* __restrict__ metric,
+                              int* __restrict__ anyvalid, int* __restrict__ usel, int* __restrict__ status,
+                              double* __restrict__ maxChange, int* __restrict__ nactive) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   bool still = false;
-  if (b < batch && status[b] == 0) {
-    const size_t B = (size_t)batch;
-    const double* uo = uerr + (long long)usel[b] * edelta + b;
-    const double* un = uerr + (long long)(1 - usel[b]) * edelta + b;
-    double mx = 0.0;
-    bool any = false;
-    for (int k = 0; k < nerr * nC; ++k) {
-      const double o = uo[(size_t)k * B], n = un[(size_t)k * B];
-      const double w = fabs(n - o) / (relTol * fabs(o) + absTol);  // :107
-      if (w == w) {                                                // MATLAB max() skips NaN
-        mx = any ? fmax(mx, w) : w;
-        any = true;
+  if (b < batch) {
+    const double mx = anyvalid[b] ? __longlong_as_double((long long)metric[b]) : __builtin_nan("");
+    metric[b] = 0ull;  // reset for the next sweep
+    anyvalid[b] = 0;
+    if (status[b] == 0) {
+      maxChange[(size_t)(sweep - 1) * batch + b] = mx;  // the value :109 prints
+      if (mx <= 1.0) {                                   // :110
+        status[b] = sweep;
+      } else {
+        usel[b] = 1 - usel[b];                           // u = uNew  :85
+        still = true;
       }
-    }
-    if (!any) mx = __builtin_nan("");
-    maxChange[(size_t)(sweep - 1) * B + b] = mx;                    // the value :109 prints
-    if (mx <= 1.0) {                                               // :110
-      status[b] = sweep;
-    } else {
-      usel[b] = 1 - usel[b];                                       // u = uNew  :85
-      still = true;
     }
   }
   const unsigned long long m = __ballot(still);
@@ -413,21 +461,23 @@ static void run_control_grid(const ControlGridArgs& a, hipStream_t s) {
   k_control_grid<P><<<dim3((a.batch + 255) / 256, 2 * a.N + 1), dim3(256), 0, s>>>(a);
 }
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx,
-                        const double* xmid, const double* lam, const double* lmid, double* u, const int* usel,
-                        long long udelta, hipStream_t s) {
-  const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, lmid, u, usel, udelta};
+                        const double* xmid, const double* lam, const double* lmid, double* u, const int* status,
+                        hipStream_t s) {
+  const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, lmid, u, status};
   OCS_DISPATCH_LOGISTIC2(p.nS, run_control_grid<P>(a, s));
   return hip_rc3(hipGetLastError());
 }
 
 template <class P>
 static void run_control_pts(const ControlPtsArgs& a, hipStream_t s) {
-  k_control_pts<P><<<dim3((a.batch + 255) / 256, a.nq), dim3(256), 0, s>>>(a);
+  k_control_pts<P><<<dim3((a.batch + 255) / 256, (a.nq + kPtsPerThread - 1) / kPtsPerThread), dim3(256), 0, s>>>(a);
 }
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
-                       const int* usel, long long odelta, hipStream_t s) {
-  const ControlPtsArgs a{nq, batch, make_tab(t), KQ, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out, usel, odelta};
+                       const int* usel, long long odelta, unsigned long long* metric, int* anyvalid, double relTol,
+                       double absTol, hipStream_t s) {
+  const ControlPtsArgs a{nq, batch, make_tab(t), KQ, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out,
+                         usel, odelta, metric, anyvalid, relTol, absTol};
   OCS_DISPATCH_LOGISTIC2(p.nS, run_control_pts<P>(a, s));
   return hip_rc3(hipGetLastError());
 }
@@ -441,10 +491,10 @@ int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hi
   return hip_rc3(hipGetLastError());
 }
 
-int launch_fbs_advance(int batch, int nerr, int nC, int sweep, double relTol, double absTol, const double* uerr,
-                       long long edelta, int* usel, int* status, double* maxChange, int* nactive, hipStream_t s) {
-  k_fbs_advance<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, nerr, nC, sweep, relTol, absTol, uerr, edelta,
-                                                                 usel, status, maxChange, nactive);
+int launch_fbs_advance(int batch, int sweep, unsigned long long* metric, int* anyvalid, int* usel, int* status,
+                       double* maxChange, int* nactive, hipStream_t s) {
+  k_fbs_advance<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, sweep, metric, anyvalid, usel, status,
+                                                                 maxChange, nactive);
   return hip_rc3(hipGetLastError());
 }
 

@@ -97,14 +97,15 @@ int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const dou
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* usel, long long udelta, double* lam, hipStream_t s);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx,
-                        const double* xmid, const double* lam, const double* lmid, double* u, const int* usel,
-                        long long udelta, hipStream_t s);
+                        const double* xmid, const double* lam, const double* lmid, double* u, const int* status,
+                        hipStream_t s);
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
-                       const int* usel, long long odelta, hipStream_t s);
+                       const int* usel, long long odelta, unsigned long long* metric, int* anyvalid, double relTol,
+                       double absTol, hipStream_t s);
 int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
-int launch_fbs_advance(int batch, int nerr, int nC, int sweep, double relTol, double absTol, const double* uerr,
-                       long long edelta, int* usel, int* status, double* maxChange, int* nactive, hipStream_t s);
+int launch_fbs_advance(int batch, int sweep, unsigned long long* metric, int* anyvalid, int* usel, int* status,
+                       double* maxChange, int* nactive, hipStream_t s);
 
 // registry queries (host)
 bool functor_supported(Functor f, int nS, int nC);
