@@ -45,6 +45,7 @@ extern "C" {
 /* ---- problem registry (device functors; see csrc/ocs_problems.hpp) ---- */
 #define OCS_PROBLEM_TEST 1     /* tests/TestOCProblem.m:22-38        params [c m r], nS=1, nC=1 */
 #define OCS_PROBLEM_LOGISTIC 2 /* LogisticK       params [c r m_1..m_nS], nC=1 */
+#define OCS_PROBLEM_USER 100   /* plugin methods given as device source (ocs_problem_create_from_source) */
 
 /* ---- control parametrisations ---- */
 #define OCS_CONTROL_PWLINEAR 1   /* Control/PWLinearControl.m   */
@@ -73,6 +74,14 @@ int ocs_synchronize(void);
  * as a registry id + parameter block (the one unavoidable change of shape). */
 int ocs_problem_create(ocs_problem *out, int problem_id, int nS, int nC, const double *params,
                        int nparams, const double *control_bounds);
+/* An OCProblem whose three plugin methods (OCProblem/OCProblem.m:8-21) are given as device C++ source and
+ * compiled at run time with hipRTC for gfx950; contract of the source: csrc/ocs_user_functor.hpp (functions
+ * ocs_F, ocs_dFdx_times_vec, ocs_dFdu_times_vec and, if has_control_char, ocs_ControlChar for fb_sweep).
+ * Runs on the lane-per-trajectory kernels.  A compile error returns OCS_ERR_INVALID with the compiler log in
+ * ocs_last_error().  ocs_problem_check_source only compiles (no GPU needed). */
+int ocs_problem_create_from_source(ocs_problem *out, const char *source, int nS, int nC, const double *params,
+                                   int nparams, const double *control_bounds, int has_control_char);
+int ocs_problem_check_source(const char *source, int nS, int nC, int nparams, int has_control_char);
 int ocs_problem_destroy(ocs_problem p);
 int ocs_problem_dims(ocs_problem p, int *nS, int *nC);
 /* Per-trajectory overrides of scalar parameters (batch extension; the reference has one

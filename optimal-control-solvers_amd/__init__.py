@@ -7,10 +7,10 @@ The directory name is not a Python identifier; load it with
 """
 from . import _lib  # noqa: F401  fails loudly when libocs.so is missing
 from ._lib import OcsError  # noqa: F401
-from .problem import OCProblem, TestOCProblem, LogisticProblem  # noqa: F401
+from .problem import OCProblem, TestOCProblem, LogisticProblem, UserProblem  # noqa: F401
 from .integrator import Integrator, RK4Integrator, RK4InfiniteIntegrator  # noqa: F401
 from .control import Control, PWLinearControl, PWConstantControl, ChebyshevControl  # noqa: F401
 from .interp import vectorInterpolant, heval  # noqa: F401
-from .solvers import nlp_objective, nlp_objective_dev, single_shooting  # noqa: F401
+from .solvers import nlp_objective, nlp_objective_dev, single_shooting, compute_equilibrium  # noqa: F401
 from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, compute_x_lam, compute_x_lam_J  # noqa: F401
 from . import distributed  # noqa: F401

@@ -44,6 +44,8 @@ _SIG = {
     "ocs_set_device": (C.c_int, [C.c_int]),
     "ocs_synchronize": (C.c_int, []),
     "ocs_problem_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]),
+    "ocs_problem_create_from_source": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]),
+    "ocs_problem_check_source": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocs_problem_destroy": (C.c_int, [vp]),
     "ocs_problem_dims": (C.c_int, [vp, ip, ip]),
     "ocs_problem_set_batch_params": (C.c_int, [vp, C.c_int, ip, C.c_int, dp]),

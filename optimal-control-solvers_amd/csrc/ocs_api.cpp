@@ -77,6 +77,7 @@ int ocs_problem_create(ocs_problem* out, int problem_id, int nS, int nC, const d
 
 int ocs_problem_destroy(ocs_problem p) {
   if (!p) return OCS_OK;
+  if (p->user) jit_free(p->user);
   p->d_ps.release();
   p->d_pb.release();
   p->d_lb.release();

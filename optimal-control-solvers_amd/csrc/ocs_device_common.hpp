@@ -13,6 +13,19 @@ typedef const double __attribute__((address_space(4))) * uniform_ptr;
 __device__ static inline uniform_ptr as_uniform(const double* p) { return (uniform_ptr)p; }
 #define PSU(p) as_uniform(p)
 
+// Where a trajectory's parameters come from: the shared block `ps` (uniform, scalar loads) or, for the
+// parameters whose bit is set in `pmask`, the per-trajectory array pb[k][batch].
+struct ParamSrc {
+  uniform_ptr ps;
+  const double* pb;
+  unsigned pmask;
+  size_t B;
+  int b;
+  __device__ inline double operator()(int k) const {
+    return ((pmask >> k) & 1u) ? pb[(size_t)k * B + b] : ps[k];
+  }
+};
+
 // ---------------------------------------------------------------------------------------
 // per-step record table
 // ---------------------------------------------------------------------------------------

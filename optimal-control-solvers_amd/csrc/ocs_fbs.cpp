@@ -155,6 +155,8 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   if (!g || !p || !x0 || !opt || !xaug || !lam || !uInterp || !J || !sweeps || batch < 1)
     return fail(OCS_ERR_INVALID, "bad argument");
   if (g->kind != 0) return fail(OCS_ERR_UNSUPPORTED, "fb_sweep needs an RK4Integrator grid");
+  if (p->user && !p->user->has_cc)
+    return fail(OCS_ERR_UNSUPPORTED, "fb_sweep needs ocs_ControlChar in the user problem source (has_control_char)");
   if (opt->nSWEEPS < 1 || opt->nERROR_PTS < 2 || opt->nINTERP_PTS < 2) return fail(OCS_ERR_INVALID, "bad options");
   if ((u0grid == nullptr) != (u0err == nullptr)) return fail(OCS_ERR_INVALID, "give both u0grid and u0err or neither");
   hipStream_t s = (hipStream_t)stream;

@@ -13,6 +13,7 @@
 #include <vector>
 
 #include "ocs_internal.hpp"
+#include "ocs_jit.hpp"
 
 namespace ocs {
 
@@ -100,6 +101,7 @@ struct ocs_problem_s {
   using Functor = ocs::Functor;
   int id = 0, nS = 0, nC = 0;
   Functor functor = Functor::Logistic;
+  ocs::UserModule* user = nullptr;  // hipRTC module of a user-supplied problem
   std::vector<double> par;      // functor order
   std::vector<int> user2func;   // user parameter index -> functor parameter index
   std::vector<double> bounds;   // nC x 2
@@ -165,6 +167,7 @@ inline ProblemDesc describe(const ocs_problem_s* p) {
   d.pmask = p->pmask;
   d.lb = p->d_lb.d();
   d.ub = p->d_ub.d();
+  d.user = p->user;
   return d;
 }
 

@@ -7,7 +7,8 @@
 namespace ocs {
 
 // Which device functor a problem handle resolves to.
-enum class Functor : int { Logistic = 1 };
+enum class Functor : int { Logistic = 1, User = 100 };
+struct UserModule;  // hipRTC-compiled user problem (ocs_jit.hpp)
 
 struct ProblemDesc {
   Functor functor;
@@ -18,6 +19,7 @@ struct ProblemDesc {
   unsigned pmask;     // bit k set -> parameter k is read from pb
   const double* lb;   // device: control lower bounds [nC]
   const double* ub;   // device: control upper bounds [nC]
+  const UserModule* user = nullptr;  // set for Functor::User
 };
 
 struct GridDesc {

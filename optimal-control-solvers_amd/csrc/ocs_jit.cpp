@@ -1,0 +1,233 @@
+// ocs_jit.cpp -- user-supplied OCProblem plugins: the three plugin methods arrive as device C++ source,
+// are compiled together with the kernel templates by hipRTC for gfx950 and loaded as a code object.
+// This restores the open plugin surface of OCProblem/OCProblem.m that the built-in registry narrows
+// (SURVEY 8(f) rank 4).  hipRTC is loaded lazily with dlopen so that libocs.so itself has no link-time
+// dependency on it.
+#include "ocs_handles.hpp"
+
+#include <dlfcn.h>
+
+#include "ocs_jit.hpp"
+
+#include "_obj/ocs_jit_sources.inc"  // generated: the kernel headers as string literals
+
+namespace ocs {
+
+typedef struct _hiprtcProgram* hiprtcProgram;
+typedef int hiprtcResult;
+struct Rtc {
+  void* lib = nullptr;
+  hiprtcResult (*CreateProgram)(hiprtcProgram*, const char*, const char*, int, const char**, const char**);
+  hiprtcResult (*CompileProgram)(hiprtcProgram, int, const char**);
+  hiprtcResult (*GetCodeSize)(hiprtcProgram, size_t*);
+  hiprtcResult (*GetCode)(hiprtcProgram, char*);
+  hiprtcResult (*GetProgramLogSize)(hiprtcProgram, size_t*);
+  hiprtcResult (*GetProgramLog)(hiprtcProgram, char*);
+  hiprtcResult (*DestroyProgram)(hiprtcProgram*);
+  hiprtcResult (*AddNameExpression)(hiprtcProgram, const char*);
+  hiprtcResult (*GetLoweredName)(hiprtcProgram, const char*, const char**);
+  const char* (*GetErrorString)(hiprtcResult);
+};
+
+static Rtc* rtc() {
+  static Rtc r;
+  static int state = 0;
+  if (state == 0) {
+    const char* names[] = {"libhiprtc.so.7", "libhiprtc.so", "/opt/rocm/lib/libhiprtc.so.7", "/opt/rocm/lib/libhiprtc.so"};
+    for (const char* n : names) {
+      r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+      if (r.lib) break;
+    }
+    state = -1;
+    if (r.lib) {
+#define L(field, sym) *(void**)(&r.field) = dlsym(r.lib, sym)
+      L(CreateProgram, "hiprtcCreateProgram");
+      L(CompileProgram, "hiprtcCompileProgram");
+      L(GetCodeSize, "hiprtcGetCodeSize");
+      L(GetCode, "hiprtcGetCode");
+      L(GetProgramLogSize, "hiprtcGetProgramLogSize");
+      L(GetProgramLog, "hiprtcGetProgramLog");
+      L(DestroyProgram, "hiprtcDestroyProgram");
+      L(AddNameExpression, "hiprtcAddNameExpression");
+      L(GetLoweredName, "hiprtcGetLoweredName");
+      L(GetErrorString, "hiprtcGetErrorString");
+#undef L
+      if (r.CreateProgram && r.CompileProgram && r.GetCodeSize && r.GetCode && r.GetProgramLogSize &&
+          r.GetProgramLog && r.DestroyProgram && r.AddNameExpression && r.GetLoweredName)
+        state = 1;
+    }
+  }
+  return state == 1 ? &r : nullptr;
+}
+
+int user_chunk(int nS) { return nS <= 4 ? 4 : 1; }
+
+static std::vector<std::string> kernel_names(int nS) {
+  const std::string ch = std::to_string(user_chunk(nS));
+  std::vector<std::string> n(UK_COUNT);
+  n[UK_TCOEF] = "ocs::k_tcoef<ocs::UserP>";
+  n[UK_BUILD_REC] = "ocs::k_build_rec<ocs::UserP>";
+  n[UK_FWD_X] = "ocs::k_forward<ocs::UserP, " + ch + ", 4, true, false>";
+  n[UK_FWD_J] = "ocs::k_forward<ocs::UserP, " + ch + ", 4, false, false>";
+  n[UK_FWD_UCONST] = "ocs::k_forward<ocs::UserP, " + ch + ", 4, true, true>";
+  n[UK_BWD_LAM_DJDU] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, true, true, false>";
+  n[UK_BWD_LAM] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, true, false, false>";
+  n[UK_BWD_DJDU] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, false, true, false>";
+  n[UK_BWD_UCONST] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, false, false, true>";
+  n[UK_EVAL] = "ocs::k_eval<ocs::UserP>";
+  n[UK_COSTATE] = "ocs::k_costate<ocs::UserP, 4>";
+  n[UK_CONTROL_GRID] = "ocs::k_control_grid<ocs::UserP>";
+  n[UK_CONTROL_PTS] = "ocs::k_control_pts<ocs::UserP>";
+  n[UK_TU_AT] = "ocs::k_tu_at<ocs::UserP>";
+  return n;
+}
+
+// Compiles the user's source.  `load` = false stops after compilation (usable without a GPU).
+int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool load, UserModule** out,
+              std::string& log) {
+  Rtc* r = rtc();
+  if (!r) {
+    log = "hipRTC (libhiprtc.so) could not be loaded";
+    return OCS_ERR_UNSUPPORTED;
+  }
+  std::string src;
+  src += "#include <hip/hip_runtime.h>\n";
+  src += "#define OCS_USER_NS " + std::to_string(nS) + "\n#define OCS_USER_NC " + std::to_string(nC) +
+         "\n#define OCS_USER_NPAR " + std::to_string(npar) + "\n";
+  if (has_cc) src += "#define OCS_USER_HAS_CONTROLCHAR 1\n";
+  src += "#include \"ocs_device_common.hpp\"\n";
+  src += "constexpr int NS = OCS_USER_NS, NC = OCS_USER_NC, NPAR = OCS_USER_NPAR;\n";
+  src += npar <= 16 ? "typedef const double* OCS_PARAMS;\n" : "typedef ocs::uniform_ptr OCS_PARAMS;\n";
+  src += "#line 1 \"user_problem\"\n";
+  src += user_src;
+  src += "\n#include \"ocs_user_functor.hpp\"\n#include \"ocs_rk4_kernels.hpp\"\n#include \"ocs_fbs_device.hpp\"\n";
+
+  const char* hdr_src[] = {src_ocs_device_common_hpp, src_ocs_user_functor_hpp, src_ocs_rk4_kernels_hpp,
+                           src_ocs_fbs_device_hpp};
+  const char* hdr_name[] = {"ocs_device_common.hpp", "ocs_user_functor.hpp", "ocs_rk4_kernels.hpp",
+                            "ocs_fbs_device.hpp"};
+  hiprtcProgram prog = nullptr;
+  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 4, hdr_src, hdr_name) != 0) {
+    log = "hiprtcCreateProgram failed";
+    return OCS_ERR_HIP;
+  }
+  const std::vector<std::string> names = kernel_names(nS);
+  for (const std::string& n : names) r->AddNameExpression(prog, n.c_str());
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
+  const hiprtcResult rc = r->CompileProgram(prog, 4, opts);
+  size_t logsz = 0;
+  r->GetProgramLogSize(prog, &logsz);
+  if (logsz > 1) {
+    log.resize(logsz);
+    r->GetProgramLog(prog, &log[0]);
+  }
+  if (rc != 0) {
+    r->DestroyProgram(&prog);
+    if (log.empty()) log = "hiprtcCompileProgram failed";
+    return OCS_ERR_INVALID;
+  }
+  UserModule* m = new UserModule();
+  m->nS = nS;
+  m->nC = nC;
+  m->npar = npar;
+  m->has_cc = has_cc;
+  m->chunk = user_chunk(nS);
+  std::vector<std::string> lowered(UK_COUNT);
+  for (int k = 0; k < UK_COUNT; ++k) {
+    const char* ln = nullptr;
+    if (r->GetLoweredName(prog, names[k].c_str(), &ln) != 0 || !ln) {
+      r->DestroyProgram(&prog);
+      delete m;
+      log = "no lowered name for " + names[k];
+      return OCS_ERR_HIP;
+    }
+    lowered[k] = ln;
+  }
+  size_t sz = 0;
+  r->GetCodeSize(prog, &sz);
+  m->code.resize(sz);
+  r->GetCode(prog, m->code.data());
+  r->DestroyProgram(&prog);
+  if (load) {
+    if (require_device() != OCS_OK) {
+      delete m;
+      log = "no HIP device to load the compiled problem on";
+      return OCS_ERR_NO_DEVICE;
+    }
+    if (hipModuleLoadData(&m->mod, m->code.data()) != hipSuccess) {
+      delete m;
+      log = "hipModuleLoadData failed";
+      return OCS_ERR_HIP;
+    }
+    for (int k = 0; k < UK_COUNT; ++k)
+      if (hipModuleGetFunction(&m->fn[k], m->mod, lowered[k].c_str()) != hipSuccess) {
+        log = "kernel " + names[k] + " missing from the compiled module";
+        (void)hipModuleUnload(m->mod);
+        delete m;
+        return OCS_ERR_HIP;
+      }
+    m->loaded = true;
+  }
+  *out = m;
+  return OCS_OK;
+}
+
+void jit_free(UserModule* m) {
+  if (!m) return;
+  if (m->loaded) (void)hipModuleUnload(m->mod);
+  delete m;
+}
+
+int jit_launch(const UserModule* m, int kid, dim3 grid, dim3 block, void** params, hipStream_t s) {
+  if (!m || !m->loaded) return -1;
+  const hipError_t e = hipModuleLaunchKernel(m->fn[kid], grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, s,
+                                             params, nullptr);
+  return e == hipSuccess ? 0 : (int)e;
+}
+
+}  // namespace ocs
+
+using namespace ocs;
+
+extern "C" {
+
+// prob = <user class>(...)  for an OCProblem whose F / dFdx_times_vec / dFdu_times_vec are given as device
+// source (OCProblem/OCProblem.m:8-21); see csrc/ocs_user_functor.hpp for the contract.
+int ocs_problem_create_from_source(ocs_problem* out, const char* source, int nS, int nC, const double* params,
+                                   int nparams, const double* control_bounds, int has_control_char) {
+  if (!out || !source || !control_bounds || (nparams > 0 && !params)) return fail(OCS_ERR_INVALID, "null argument");
+  *out = nullptr;
+  if (nS < 1 || nS > 64 || nC < 1 || nC > 8 || nparams < 0) return fail(OCS_ERR_SHAPE, "need 1 <= nS <= 64, 1 <= nC <= 8");
+  std::string log;
+  UserModule* m = nullptr;
+  const int rc = jit_build(source, nS, nC, nparams, has_control_char != 0, true, &m, log);
+  if (rc != OCS_OK) return fail(rc, "user problem: %s", log.substr(0, 400).c_str());
+  ocs_problem_s* p = new ocs_problem_s();
+  p->id = OCS_PROBLEM_USER;
+  p->nS = nS;
+  p->nC = nC;
+  p->functor = Functor::User;
+  p->user = m;
+  p->par.assign(params, params + nparams);
+  if (p->par.empty()) p->par.push_back(0.0);
+  p->user2func.resize(nparams);
+  for (int k = 0; k < nparams; ++k) p->user2func[k] = k;
+  p->bounds.assign(control_bounds, control_bounds + 2 * nC);
+  p->version = next_version();
+  *out = p;
+  return OCS_OK;
+}
+
+// Compile-only check of a user problem (no GPU needed): 0 if the source builds for gfx950, else the
+// compiler log is in ocs_last_error().
+int ocs_problem_check_source(const char* source, int nS, int nC, int nparams, int has_control_char) {
+  if (!source) return fail(OCS_ERR_INVALID, "null argument");
+  std::string log;
+  UserModule* m = nullptr;
+  const int rc = jit_build(source, nS, nC, nparams, has_control_char != 0, false, &m, log);
+  if (rc != OCS_OK) return fail(rc, "user problem: %s", log.substr(0, 400).c_str());
+  jit_free(m);
+  return OCS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,28 @@
+// ocs_jit.hpp -- private interface of the hipRTC path for user-supplied problems.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+namespace ocs {
+
+enum UserKernel : int {
+  UK_TCOEF = 0, UK_BUILD_REC, UK_FWD_X, UK_FWD_J, UK_FWD_UCONST, UK_BWD_LAM_DJDU, UK_BWD_LAM, UK_BWD_DJDU,
+  UK_BWD_UCONST, UK_EVAL, UK_COSTATE, UK_CONTROL_GRID, UK_CONTROL_PTS, UK_TU_AT, UK_COUNT
+};
+
+struct UserModule {
+  int nS = 0, nC = 0, npar = 0, chunk = 4;
+  bool has_cc = false, loaded = false;
+  std::vector<char> code;
+  hipModule_t mod = nullptr;
+  hipFunction_t fn[UK_COUNT] = {};
+};
+
+int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool load, UserModule** out,
+              std::string& log);
+void jit_free(UserModule* m);
+int jit_launch(const UserModule* m, int kid, dim3 grid, dim3 block, void** params, hipStream_t s);
+
+}  // namespace ocs

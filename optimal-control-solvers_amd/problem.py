@@ -86,6 +86,28 @@ class OCProblem:
         return out
 
 
+class UserProblem(OCProblem):
+    """An OCProblem subclass written by the user: the three plugin methods F, dFdx_times_vec and
+    dFdu_times_vec (OCProblem/OCProblem.m:8-21) are given as device C++ source (functions ocs_F,
+    ocs_dFdx_times_vec, ocs_dFdu_times_vec, optionally ocs_ControlChar; contract in
+    csrc/ocs_user_functor.hpp) and compiled with hipRTC for gfx950 when the object is created."""
+
+    def __init__(self, source, nS, nC, params, ControlBounds, has_control_char=False):
+        self.nS, self.nC, self.nAug = int(nS), int(nC), int(nS) + 1
+        self.params = _f(params).ravel()
+        self.ControlBounds = _f(ControlBounds, (self.nC, 2))
+        self.source = source
+        h = C.c_void_p()
+        check(lib.ocs_problem_create_from_source(C.byref(h), source.encode(), self.nS, self.nC, _p(self.params),
+                                                 self.params.size, _p(self.ControlBounds), int(has_control_char)))
+        self._h = h
+
+    @staticmethod
+    def check_source(source, nS, nC, nparams, has_control_char=False):
+        """Compile only (works without a GPU); raises OcsError with the compiler log on failure."""
+        check(lib.ocs_problem_check_source(source.encode(), int(nS), int(nC), int(nparams), int(has_control_char)))
+
+
 class TestOCProblem(OCProblem):
     """tests/TestOCProblem.m:16-20: prob = TestOCProblem(p, ControlBounds), p has fields c, m, r."""
     __test__ = False

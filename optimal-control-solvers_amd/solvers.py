@@ -117,3 +117,35 @@ def single_shooting(prob, x0, tspan, nCONTROL_PTS, **kw):
     soln["lam"] = vectorInterpolant(tspan, lamOpt[:-1, :], "pchip")              # :130
     soln["_v"], soln["_nfev"], soln["_message"] = vOpt, res.nfev, res.message
     return soln
+
+
+def compute_equilibrium(prob, xGuess, lamGuess, uGuess, lb, ub, r):
+    """[xStar, lamStar, uStar, resnorm, residual, exitflag] = compute_equilibrium(prob, xGuess, lamGuess,
+    uGuess, lb, ub, r)   functions/compute_equilibrium.m:1-34.
+    Steady state of the optimality system: F(0,x,u)(1:nS) = 0, r*lam - dFdx_times_vec(0,x,u,[lam;1])(1:nS) = 0,
+    dFdu_times_vec(0,x,u,[lam;1]) = 0 (:10-21).  The plugin methods are evaluated by the device functor; the
+    bounded nonlinear least-squares driver is scipy's trust-region-reflective `least_squares`, the algorithm
+    family of MATLAB's lsqnonlin (a toolbox that does not exist here), with the reference's TolFun 1e-10."""
+    from scipy.optimize import least_squares
+    xGuess, lamGuess, uGuess = (np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in (xGuess, lamGuess, uGuess))
+    nS, nC = xGuess.size, uGuess.size
+    xi, li, ui = slice(0, nS), slice(nS, 2 * nS), slice(2 * nS, 2 * nS + nC)
+
+    def equilibrium_system(y):                                            # :13-21
+        x, lam, u = y[xi], y[li], y[ui]
+        ya = np.concatenate([x, [0.0]])
+        va = np.concatenate([lam, [1.0]])
+        value = np.zeros_like(y)
+        value[xi] = prob.F(0.0, ya, u)[:nS, 0]
+        value[li] = r * lam - prob.dFdx_times_vec(0.0, ya, u, va)[:nS, 0]
+        value[ui] = prob.dFdu_times_vec(0.0, ya, u, va)[:, 0]
+        return value
+
+    y0 = np.concatenate([xGuess, lamGuess, uGuess])
+    lb = np.asarray(lb, dtype=np.float64).ravel()
+    ub = np.asarray(ub, dtype=np.float64).ravel()
+    y0 = np.minimum(np.maximum(y0, lb), ub)
+    res = least_squares(equilibrium_system, y0, bounds=(lb, ub), method="trf", ftol=1e-10, xtol=1e-14, gtol=1e-14,
+                        max_nfev=1000 * (2 * nS + nC))                    # :23-27
+    y = res.x
+    return y[xi], y[li], y[ui], float(2 * res.cost), res.fun, int(res.status)

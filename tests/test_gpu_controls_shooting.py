@@ -167,3 +167,21 @@ def test_single_shooting_end_to_end(ocs, oracle):
     assert np.max(np.abs(soln["u"](tq) - us)) < 2e-2
     assert np.max(np.abs(soln["x"](tq) - 2.7355691886341361)) < 2e-2
     assert soln["x"](np.array([0.0]))[0, 0] == 1.0 and soln["lam"](tq).shape == (1, 3)
+
+
+def test_compute_equilibrium_and_solve_test_problem_script(ocs, oracle):
+    """tests/solve_test_problem.m:21-39 end to end: equilibrium (analytic KAT 1) -> RK4InfiniteIntegrator with
+    uStar -> single_shooting with that integrator (the line the reference leaves commented out, :38-39)."""
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    lb, ub = [0.0, -np.inf, 0.0], [np.inf, np.inf, 1.0]                          # :25-26
+    xs, ls, us, resnorm, _, flag = ocs.compute_equilibrium(prob, 2.7, 2.2, 0.7, lb, ub, P["r"])  # :27-29
+    assert flag > 0 and resnorm < 1e-20
+    assert abs(xs[0] - 2.7355691886341361) < 1e-9 and abs(ls[0] - 2.1701063402939477) < 1e-9
+    assert abs(us[0] - 0.72336878009798256) < 1e-9
+    tspan, tx = oracle.linspace(0, 10, 201), oracle.linspace(10, 20, 201)
+    integ = ocs.RK4InfiniteIntegrator(tspan, tx, us)                              # :33
+    soln = ocs.single_shooting(prob, [1.0], tspan, 41, u0=us, Integrator=integ)   # :37-39
+    # with the tail leg the optimal control stays on the turnpike up to the end of the horizon
+    assert abs(soln["u"](np.array([9.5]))[0, 0] - us[0]) < 2e-2
+    plain = ocs.single_shooting(prob, [1.0], tspan, 41, u0=us)
+    assert plain["u"](np.array([10.0]))[0, 0] < 0.2  # finite horizon: harvest drops at the end (lam(T) = 0)

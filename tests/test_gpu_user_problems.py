@@ -1,0 +1,122 @@
+"""GPU parity of user-written OCProblem plugins compiled with hipRTC -- the open
+plugin surface of OCProblem/OCProblem.m -- including a coupled problem that is not in the registry, and
+the build-defined LQ problem of BASELINE config 5 (nC > 1, RK4InfiniteIntegrator) at a reduced size."""
+import numpy as np
+import pytest
+
+from oracle import np_twin as tw
+from tests.user_problems import (LOGISTIC2_SRC, PREDPREY_PARAMS, PREDPREY_SRC, PredPreyNP, lq_matrices, lq_source)
+
+pytestmark = pytest.mark.gpu
+RTOL = 1e-12
+BOUNDS = [[0.0, 1.0]]
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+
+
+@pytest.fixture(scope="module")
+def ocs():
+    import torch
+    assert torch.cuda.is_available()
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+def test_hand_written_logistic2_equals_builtin_and_oracle(ocs, oracle):
+    c, r, m = 1.5, 0.05, [3.0, 2.5]
+    pu = ocs.UserProblem(LOGISTIC2_SRC, 2, 1, [c, r] + m, BOUNDS, has_control_char=True)
+    pb, po = ocs.LogisticProblem(m, c, r, BOUNDS), oracle.LogisticProblem(m, c, r, BOUNDS)
+    rng = np.random.default_rng(1)
+    t, y = rng.uniform(0, 10, 9), rng.normal(1.5, 0.5, (3, 9))
+    u, v = rng.uniform(0, 1, (1, 9)), rng.normal(size=(3, 9))
+    assert relerr(pu.F(t, y, u), po.F(t, y, u)) < 1e-14
+    assert relerr(pu.dFdx_times_vec(t, y, u, v), po.dFdx_times_vec(t, y, u, v)) < 1e-14
+    assert relerr(pu.dFdu_times_vec(t, y, u, v), po.dFdu_times_vec(t, y, u, v)) < 1e-14
+    N, batch = 203, 70
+    tspan = oracle.linspace(0, 10, N + 1)
+    uu = rng.uniform(0.05, 0.45, (1, 2 * N + 1, batch))
+    x0 = rng.uniform(0.9, 2.0, (2, batch))
+    g = ocs.RK4Integrator(tspan)
+    x, J = g.compute_states(pu, x0, uu)
+    lam, dJdu = g.compute_adjoints(pu, uu)
+    ref = oracle.batch_states_adjoints(po, tspan, x0, uu)
+    assert relerr(x, ref["x"]) < RTOL and relerr(J, ref["J"]) < RTOL
+    assert relerr(lam, ref["lam"]) < RTOL and relerr(dJdu, ref["dJdu"]) < RTOL
+    xb, Jb = g.compute_states(pb, x0, uu)
+    assert relerr(x, xb) < 1e-13
+    # per-trajectory parameter override works for user problems with <= 16 parameters
+    cs = rng.uniform(1, 2, batch)
+    pu.set_batch_params([0], cs[None, :])
+    _, Jc = g.compute_states(pu, x0, uu)
+    go = oracle.RK4Integrator(tspan)
+    _, Jo = go.compute_states(oracle.LogisticProblem(m, cs[5], r, BOUNDS), x0[:, 5], uu[:, :, 5])
+    assert abs(Jc[5] - Jo) < RTOL * abs(Jo)
+    pu.set_batch_params([], None)
+    # fb_sweep through the user's ocs_ControlChar
+    s1 = ocs.fb_sweep_batch(pu, np.array([[1.0], [1.5]]), oracle.linspace(0, 8, 161), {"nERROR_PTS": 161, "nINTERP_PTS": 81})
+    s2 = oracle.fb_sweep(po, [1.0, 1.5], oracle.linspace(0, 8, 161), {"nERROR_PTS": 161, "nINTERP_PTS": 81})
+    assert s1["sweeps"][0] == s2["_sweeps"] > 0 and abs(s1["J"][0] - s2["J"]) < 1e-10 * abs(s2["J"])
+    assert relerr(s1["u"][:, :, 0], s2["u"]) < 1e-10
+
+
+def test_coupled_problem_outside_the_registry(ocs, oracle):
+    pu, pn = ocs.UserProblem(PREDPREY_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS), PredPreyNP()
+    N, batch = 120, 66
+    tspan = oracle.linspace(0, 6, N + 1)
+    rng = np.random.default_rng(2)
+    uu = rng.uniform(0.0, 1.0, (1, 2 * N + 1, batch))
+    x0 = rng.uniform(1.0, 2.5, (2, batch))
+    g = ocs.RK4Integrator(tspan)
+    x, J = g.compute_states(pu, x0, uu)
+    lam, dJdu = g.compute_adjoints(pu, uu)
+    gn = tw.RK4IntegratorNP(tspan)
+    for b in (0, 1, 64, 65):
+        xn, Jn = gn.compute_states(pn, x0[:, b], uu[:, :, b])
+        lamn, dn = gn.compute_adjoints(pn, uu[:, :, b])
+        assert relerr(x[:, :, b], xn) < RTOL and abs(J[b] - Jn) < RTOL * max(1, abs(Jn))
+        assert relerr(lam[:, :, b], lamn) < RTOL and relerr(dJdu[:, :, b], dn) < RTOL
+    # objective + gradient through a control basis; gradient exactness by complex step on the NumPy twin
+    ctrl = ocs.PWLinearControl(g.t, 7, 1)
+    v = rng.uniform(0.1, 0.9, 7)
+    Jg, dJdv, _ = ocs.nlp_objective(g, pu, ctrl, x0[:, 0], v)
+    cs = np.empty(7)
+    for i in range(7):
+        vc = v.astype(complex)
+        vc[i] += 1e-30j
+        cs[i] = gn.compute_states(pn, x0[:, 0].astype(complex), vc[None, :] @ ctrl.B)[1].imag / 1e-30
+    assert relerr(dJdv, cs) < 1e-11
+    with pytest.raises(ocs.OcsError):
+        ocs.fb_sweep_batch(pu, x0[:, :1], tspan)  # no ocs_ControlChar in this plugin
+
+
+def test_lq_problem_bl5_style(ocs, oracle):
+    """BASELINE config 5 at reduced size: LQ with a dense shared A, nC = 2, RK4InfiniteIntegrator with uStar = 0."""
+    nS, nC, N, batch = 6, 2, 160, 68
+    A, Bu, q, rdiag = lq_matrices(nS, nC)
+    r = 0.05
+    par = np.concatenate([[r], A.ravel(order="F"), Bu.ravel(order="F"), q, rdiag])
+    bounds = [[-1.0, 1.0]] * nC
+    pu = ocs.UserProblem(lq_source(nS, nC), nS, nC, par, bounds)
+    po = oracle.LQProblem(A, Bu, q, rdiag, r, bounds)
+    tspan, tx = oracle.linspace(0, 2, N + 1), oracle.linspace(2, 4, N + 1)
+    rng = np.random.default_rng(3)
+    u = rng.uniform(-1, 1, (nC, 2 * N + 1, batch))
+    x0 = rng.normal(size=(nS, batch))
+    gi, go = ocs.RK4InfiniteIntegrator(tspan, tx, np.zeros(nC)), oracle.RK4InfiniteIntegrator(tspan, tx, np.zeros(nC))
+    x, J = gi.compute_states(pu, x0, u)
+    lam, dJdu = gi.compute_adjoints(pu, u)
+    for b in (0, 1, 66, 67):
+        xo, Jo = go.compute_states(po, x0[:, b], u[:, :, b])
+        lamo, do = go.compute_adjoints(po, u[:, :, b])
+        assert relerr(x[:, :, b], xo) < RTOL and abs(J[b] - Jo) < RTOL * max(1, abs(Jo))
+        assert relerr(lam[:, :, b], lamo) < RTOL and relerr(dJdu[:, :, b], do) < RTOL
+    # nC = 2 through the control bases and the shooting objective
+    cg, co = ocs.PWConstantControl(gi.t, 5, nC), oracle.PWConstantControl(go.t, 5, nC)
+    V = rng.uniform(-1, 1, (nC * 5, 3))
+    Jn, dJdv, _ = ocs.nlp_objective(gi, pu, cg, x0[:, :3], V)
+    for b in range(3):
+        Jo, do, _ = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b])
+        assert abs(Jn[b] - Jo) < RTOL * max(1, abs(Jo)) and relerr(dJdv[:, b], do) < RTOL

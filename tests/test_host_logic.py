@@ -67,3 +67,15 @@ def test_vector_interpolant_matches_oracle(ocs, oracle):
     assert one.shape == (1, q.size) and np.array_equal(one[0], got[0] * 0 + ocs.vectorInterpolant(x, v[:1], "pchip")(q)[0])
     assert np.array_equal(ocs.heval(ocs.vectorInterpolant(x, v, "linear"), q, [2, 0]),
                           oracle.vector_interp(x, v, oracle.INTERP_LINEAR, q)[[2, 0]])
+
+
+def test_user_problem_sources_compile_for_gfx950(ocs):
+    """hipRTC path (SURVEY 8(f) rank 4): user plugin source + kernel templates compile without a GPU;
+    a broken plugin reports the compiler's message."""
+    from tests.user_problems import LOGISTIC2_SRC, PREDPREY_SRC, lq_source
+    ocs.UserProblem.check_source(LOGISTIC2_SRC, 2, 1, 4, has_control_char=True)
+    ocs.UserProblem.check_source(PREDPREY_SRC, 2, 1, 8)
+    ocs.UserProblem.check_source(lq_source(6, 2), 6, 2, 1 + 36 + 12 + 6 + 2)   # > 16 parameters: uniform block
+    with pytest.raises(ocs.OcsError) as e:
+        ocs.UserProblem.check_source("__device__ void ocs_F(double t) { syntax error }", 1, 1, 0)
+    assert e.value.code == -1 and "error" in str(e.value)

@@ -1,0 +1,125 @@
+"""User-written OCProblem plugins used by the tests: device source for the hipRTC path next to a NumPy
+restatement of the same three methods (for oracle/np_twin.RK4IntegratorNP)."""
+import numpy as np
+
+# ---- LogisticK with nS = 2 written by hand (must agree with the built-in functor and the C oracle) ----
+LOGISTIC2_SRC = r"""
+// params: [c, r, m1, m2]
+__device__ void ocs_F(double t, const double* y, const double* u, OCS_PARAMS p, double* f) {
+  f[0] = y[0] * (p[2] - y[0]) - u[0];
+  f[1] = y[1] * (p[3] - y[1]) - u[0];
+  f[2] = exp(-p[1] * t) * (y[0] * y[0] + y[1] * y[1] + p[0] * u[0] * u[0]);
+}
+__device__ void ocs_dFdx_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  const double e = exp(-p[1] * t);
+  g[0] = (p[2] - 2 * y[0]) * v[0] + 2 * e * y[0] * v[2];
+  g[1] = (p[3] - 2 * y[1]) * v[1] + 2 * e * y[1] * v[2];
+}
+__device__ void ocs_dFdu_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  g[0] = -v[0] - v[1] + 2 * p[0] * exp(-p[1] * t) * u[0] * v[2];
+}
+__device__ void ocs_ControlChar(double t, const double* x, const double* lam, OCS_PARAMS p, const double* lb,
+                                const double* ub, double* u) {
+  u[0] = fmin(ub[0], fmax(lb[0], (lam[0] + lam[1]) * exp(p[1] * t) / (2 * p[0])));
+}
+"""
+
+# ---- predator-prey with harvested predator: coupled, not row-separable, not in the registry ----
+# x1' = x1 (al - be x2),  x2' = x2 (de x1 - ga) - u x2,  cost' = e^{-rt} (c u^2 + q (x1 - xb)^2)
+# params: [al, be, de, ga, c, q, xb, r]
+PREDPREY_SRC = r"""
+__device__ void ocs_F(double t, const double* y, const double* u, OCS_PARAMS p, double* f) {
+  f[0] = y[0] * (p[0] - p[1] * y[1]);
+  f[1] = y[1] * (p[2] * y[0] - p[3]) - u[0] * y[1];
+  const double d = y[0] - p[6];
+  f[2] = exp(-p[7] * t) * (p[4] * u[0] * u[0] + p[5] * d * d);
+}
+__device__ void ocs_dFdx_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  const double e = exp(-p[7] * t);
+  g[0] = (p[0] - p[1] * y[1]) * v[0] + p[2] * y[1] * v[1] + e * 2 * p[5] * (y[0] - p[6]) * v[2];
+  g[1] = -p[1] * y[0] * v[0] + (p[2] * y[0] - p[3] - u[0]) * v[1];
+}
+__device__ void ocs_dFdu_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  g[0] = -y[1] * v[1] + exp(-p[7] * t) * 2 * p[4] * u[0] * v[2];
+}
+"""
+PREDPREY_PARAMS = [1.0, 0.5, 0.3, 0.6, 2.0, 1.5, 1.8, 0.05]
+
+
+class PredPreyNP:
+    """NumPy twin of PREDPREY_SRC with the OCProblem method signatures (columns vectorised)."""
+    nS, nC = 2, 1
+
+    def __init__(self, p=PREDPREY_PARAMS):
+        self.p = np.asarray(p, dtype=np.float64)
+
+    def F(self, t, y, u):
+        p = self.p
+        d = y[0] - p[6]
+        return np.vstack([y[0] * (p[0] - p[1] * y[1]), y[1] * (p[2] * y[0] - p[3]) - u[0] * y[1],
+                          np.exp(-p[7] * t) * (p[4] * u[0] * u[0] + p[5] * d * d)])
+
+    def dFdx_times_vec(self, t, y, u, v):
+        p = self.p
+        e = np.exp(-p[7] * t)
+        g0 = (p[0] - p[1] * y[1]) * v[0] + p[2] * y[1] * v[1] + e * 2 * p[5] * (y[0] - p[6]) * v[2]
+        g1 = -p[1] * y[0] * v[0] + (p[2] * y[0] - p[3] - u[0]) * v[1]
+        return np.vstack([g0, g1, np.zeros_like(g0)])
+
+    def dFdu_times_vec(self, t, y, u, v):
+        p = self.p
+        return (-y[1] * v[1] + np.exp(-p[7] * t) * 2 * p[4] * u[0] * v[2])[None, :]
+
+
+def lq_source(nS, nC):
+    """Device source of the build-defined LQ problem (SURVEY BL-5): F = [A x + Bu u ; e^{-rt}(x'Qx + u'Ru)],
+    params [r | A (nS x nS col-major) | Bu (nS x nC) | q (nS) | rdiag (nC)] as in oracle/ocs_oracle.c."""
+    oA, oB, oq, oR = 1, 1 + nS * nS, 1 + nS * nS + nS * nC, 1 + nS * nS + nS * nC + nS
+    return f"""
+__device__ void ocs_F(double t, const double* y, const double* u, OCS_PARAMS p, double* f) {{
+  double s = 0.0;
+#pragma unroll
+  for (int i = 0; i < {nS}; ++i) {{
+    double a = 0.0;
+#pragma unroll
+    for (int l = 0; l < {nS}; ++l) a += p[{oA} + i + {nS} * l] * y[l];
+#pragma unroll
+    for (int l = 0; l < {nC}; ++l) a += p[{oB} + i + {nS} * l] * u[l];
+    f[i] = a;
+    s += p[{oq} + i] * (y[i] * y[i]);
+  }}
+#pragma unroll
+  for (int l = 0; l < {nC}; ++l) s += p[{oR} + l] * (u[l] * u[l]);
+  f[{nS}] = exp(-p[0] * t) * s;
+}}
+__device__ void ocs_dFdx_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {{
+  const double e = exp(-p[0] * t);
+#pragma unroll
+  for (int i = 0; i < {nS}; ++i) {{
+    double a = 0.0;
+#pragma unroll
+    for (int l = 0; l < {nS}; ++l) a += p[{oA} + l + {nS} * i] * v[l];
+    g[i] = a + 2 * e * p[{oq} + i] * y[i] * v[{nS}];
+  }}
+}}
+__device__ void ocs_dFdu_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {{
+  const double e = exp(-p[0] * t);
+#pragma unroll
+  for (int l = 0; l < {nC}; ++l) {{
+    double a = 0.0;
+#pragma unroll
+    for (int i = 0; i < {nS}; ++i) a += p[{oB} + i + {nS} * l] * v[i];
+    g[l] = a + 2 * e * p[{oR} + l] * u[l] * v[{nS}];
+  }}
+}}
+"""
+
+
+def lq_matrices(nS, nC, seed=20260405):
+    """BL-5 style data: A = -diag(logspace(0, 1.5, nS)) + 0.1 G, seeded (mildly stiff for test step sizes)."""
+    rng = np.random.default_rng(seed)
+    A = -np.diag(np.logspace(0, 1.5, nS)) + 0.1 * rng.normal(size=(nS, nS))
+    Bu = rng.normal(size=(nS, nC))
+    q = rng.uniform(0.5, 1.5, nS)
+    rdiag = rng.uniform(1.0, 2.0, nC)
+    return A, Bu, q, rdiag
