@@ -13,7 +13,8 @@ struct ocs_control_s {
   std::vector<double> t, pts, B;  // B: nBasis x nT column-major (property B)
   double t0 = 0, t1 = 0;
   // device copies: CSC (for u = v*B) and CSR (for dJdv = dJdu*B')
-  DevBuf d_colptr, d_row, d_cval, d_rowptr, d_col, d_rval;
+  DevBuf d_colptr, d_row, d_cval, d_rowptr, d_col, d_rval, d_BT;
+  bool dense = false;  // more than half of B is non-zero and nBasis <= 32: register-resident dense kernels
   bool uploaded = false;
   hipStream_t stream = nullptr;
   DevBuf d_v, d_u, d_dJdu, d_dJdv, d_stage, d_x0, d_J, d_idx;
@@ -134,6 +135,16 @@ static int upload_control(ocs_control_s* c) {
   HIP_TRY(hipMemcpy(c->d_rowptr.p, rowptr.data(), sizeof(int) * rowptr.size(), hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_col.p, col.data(), sizeof(int) * nnz, hipMemcpyHostToDevice));
   HIP_TRY(hipMemcpy(c->d_rval.p, rval.data(), sizeof(double) * nnz, hipMemcpyHostToDevice));
+  size_t nz = 0;
+  for (double b : c->B) nz += (b != 0.0);
+  c->dense = basis_dense_supported(nB) && 2 * nz > c->B.size();
+  if (c->dense) {
+    std::vector<double> BT((size_t)nT * nB);
+    for (int j = 0; j < nT; ++j)
+      for (int i = 0; i < nB; ++i) BT[(size_t)j * nB + i] = c->B[i + (size_t)nB * j];
+    OCS_TRY(c->d_BT.ensure(sizeof(double) * BT.size()));
+    HIP_TRY(hipMemcpy(c->d_BT.p, BT.data(), sizeof(double) * BT.size(), hipMemcpyHostToDevice));
+  }
   if (!c->stream) HIP_TRY(hipStreamCreate(&c->stream));
   c->uploaded = true;
   return OCS_OK;
@@ -211,7 +222,7 @@ int ocs_control_create(ocs_control* out, int kind, const double* t, int nt, int 
 int ocs_control_destroy(ocs_control c) {
   if (!c) return OCS_OK;
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  DevBuf* bufs[] = {&c->d_colptr, &c->d_row, &c->d_cval, &c->d_rowptr, &c->d_col, &c->d_rval, &c->d_v,
+  DevBuf* bufs[] = {&c->d_colptr, &c->d_row, &c->d_cval, &c->d_rowptr, &c->d_col, &c->d_rval, &c->d_BT, &c->d_v,
                     &c->d_u, &c->d_dJdu, &c->d_dJdv, &c->d_stage, &c->d_x0, &c->d_J, &c->d_idx};
   for (DevBuf* b : bufs) b->release();
   delete c;
@@ -239,6 +250,10 @@ int ocs_control_points(ocs_control c, double* pts) {
 int ocs_control_compute_u_dev(ocs_control c, int batch, const double* v, double* u, void* stream) {
   if (!c || !v || !u || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_control(c));
+  if (c->dense && batch >= 16384) {  // below that the time-parallel sparse kernel fills the chip better
+    LAUNCH_TRY(launch_basis_dense(true, c->nBasis, c->nT, c->nC, batch, c->d_BT.d(), v, u, (hipStream_t)stream));
+    return OCS_OK;
+  }
   LAUNCH_TRY(launch_basis_expand(c->nT, c->nC, batch, (const int*)c->d_colptr.p, (const int*)c->d_row.p,
                                  c->d_cval.d(), v, u, (hipStream_t)stream));
   return OCS_OK;
@@ -247,6 +262,10 @@ int ocs_control_compute_u_dev(ocs_control c, int batch, const double* v, double*
 int ocs_control_compute_dJdv_dev(ocs_control c, int batch, const double* dJdu, double* dJdv, void* stream) {
   if (!c || !dJdu || !dJdv || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_control(c));
+  if (c->dense && batch >= 16384) {
+    LAUNCH_TRY(launch_basis_dense(false, c->nBasis, c->nT, c->nC, batch, c->d_BT.d(), dJdu, dJdv, (hipStream_t)stream));
+    return OCS_OK;
+  }
   LAUNCH_TRY(launch_basis_contract(c->nBasis, c->nC, batch, (const int*)c->d_rowptr.p, (const int*)c->d_col.p,
                                    c->d_rval.d(), dJdu, dJdv, (hipStream_t)stream));
   return OCS_OK;

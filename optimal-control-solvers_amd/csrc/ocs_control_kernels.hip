@@ -46,6 +46,73 @@ __global__ __launch_bounds__(256) void k_basis_contract(int nBasis, int nC, int 
   }
 }
 
+// Dense bases (Chebyshev): one thread per trajectory keeps all NB coefficients / accumulators in registers
+// and streams over time once, reading the basis column of each grid point as a wave-uniform row of the
+// transposed table BT [nT][NB] -- dJdu is then read once instead of once per basis function.
+// Accumulation order over j (ascending) and over i (ascending) is the reference's dense product.
+template <int NB>
+__global__ __launch_bounds__(64) void k_basis_expand_dense(int nT, int nC, int batch, const double* __restrict__ BT,
+                                                           const double* __restrict__ v, double* __restrict__ u) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (b >= batch) return;
+  const size_t B = (size_t)batch;
+  double vv[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) vv[i] = v[((size_t)i * nC + c) * B + b];
+  for (int j = 0; j < nT; ++j) {
+    const double* bt = BT + (size_t)j * NB;
+    double acc = 0.0;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc += vv[i] * bt[i];
+    u[((size_t)j * nC + c) * B + b] = acc;
+  }
+}
+template <int NB>
+__global__ __launch_bounds__(64) void k_basis_contract_dense(int nT, int nC, int batch, const double* __restrict__ BT,
+                                                             const double* __restrict__ dJdu, double* __restrict__ dJdv) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y;
+  if (b >= batch) return;
+  const size_t B = (size_t)batch;
+  double acc[NB];
+#pragma unroll
+  for (int i = 0; i < NB; ++i) acc[i] = 0.0;
+  for (int j = 0; j < nT; ++j) {
+    const double* bt = BT + (size_t)j * NB;
+    const double d = dJdu[((size_t)j * nC + c) * B + b];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) acc[i] += d * bt[i];
+  }
+#pragma unroll
+  for (int i = 0; i < NB; ++i) dJdv[((size_t)i * nC + c) * B + b] = acc[i];
+}
+
+template <int NB>
+static void run_dense(bool expand, int nT, int nC, int batch, const double* BT, const double* in, double* out,
+                      hipStream_t s) {
+  const dim3 grid((batch + 63) / 64, nC), block(64);
+  if (expand)
+    k_basis_expand_dense<NB><<<grid, block, 0, s>>>(nT, nC, batch, BT, in, out);
+  else
+    k_basis_contract_dense<NB><<<grid, block, 0, s>>>(nT, nC, batch, BT, in, out);
+}
+bool basis_dense_supported(int nBasis) { return nBasis >= 1 && nBasis <= 32; }
+// BT: transposed basis [nT][nBasis].  expand: in = v, out = u; else in = dJdu, out = dJdv.
+int launch_basis_dense(bool expand, int nBasis, int nT, int nC, int batch, const double* BT, const double* in,
+                       double* out, hipStream_t s) {
+  switch (nBasis) {
+#define OCS_NB(n) case n: run_dense<n>(expand, nT, nC, batch, BT, in, out, s); break;
+    OCS_NB(1) OCS_NB(2) OCS_NB(3) OCS_NB(4) OCS_NB(5) OCS_NB(6) OCS_NB(7) OCS_NB(8)
+    OCS_NB(9) OCS_NB(10) OCS_NB(11) OCS_NB(12) OCS_NB(13) OCS_NB(14) OCS_NB(15) OCS_NB(16)
+    OCS_NB(17) OCS_NB(18) OCS_NB(19) OCS_NB(20) OCS_NB(21) OCS_NB(22) OCS_NB(23) OCS_NB(24)
+    OCS_NB(25) OCS_NB(26) OCS_NB(27) OCS_NB(28) OCS_NB(29) OCS_NB(30) OCS_NB(31) OCS_NB(32)
+#undef OCS_NB
+    default: return -1;
+  }
+  return hip_rc2(hipGetLastError());
+}
+
 // dst[r][b] = src[idx[r]][b]   (gathers rows of a batch-minor array; used for lam(FreeInitStates,1))
 __global__ void k_gather_rows(int nrows, int batch, const int* __restrict__ idx, const double* __restrict__ src,
                               double* __restrict__ dst) {

@@ -82,6 +82,9 @@ int launch_basis_expand(int nT, int nC, int batch, const int* colptr, const int*
                         const double* v, double* u, hipStream_t s);
 int launch_basis_contract(int nBasis, int nC, int batch, const int* rowptr, const int* col, const double* val,
                           const double* dJdu, double* dJdv, hipStream_t s);
+bool basis_dense_supported(int nBasis);
+int launch_basis_dense(bool expand, int nBasis, int nT, int nC, int batch, const double* BT, const double* in,
+                       double* out, hipStream_t s);
 int launch_fill_rows(int ncols, int nC, int batch, const double* val, double* out, hipStream_t s);
 int launch_gather_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
 int launch_scatter_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
