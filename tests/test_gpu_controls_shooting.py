@@ -185,3 +185,46 @@ def test_compute_equilibrium_and_solve_test_problem_script(ocs, oracle):
     assert abs(soln["u"](np.array([9.5]))[0, 0] - us[0]) < 2e-2
     plain = ocs.single_shooting(prob, [1.0], tspan, 41, u0=us)
     assert plain["u"](np.array([10.0]))[0, 0] < 0.2  # finite horizon: harvest drops at the end (lam(T) = 0)
+
+
+def test_single_shooting_batch_on_device(ocs, oracle):
+    """a batch of independent shooting NLPs (different x0 and c) solved together by the
+    batched projected-gradient driver; every instance must reach the optimum the oracle-driven SLSQP finds."""
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(12)
+    B, N, nPts = 24, 200, 21
+    tspan = oracle.linspace(0, 10, N + 1)
+    x0 = rng.uniform(0.6, 2.4, (1, B))
+    cs = rng.uniform(1.0, 2.0, B)
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    r = ocs.single_shooting_batch(prob, x0, tspan, nPts, u0=0.7, TolFun=1e-6, MaxIter=400)
+    J = r["J"].cpu().numpy()
+    assert bool(r["converged"].all())
+    go = oracle.RK4Integrator(tspan)
+    co = oracle.PWLinearControl(go.t, nPts, 1)
+    for b in (0, 7, 23):
+        po = oracle.TestOCProblem({"c": cs[b], "m": P["m"], "r": P["r"]}, BOUNDS)
+        res = minimize(lambda v: oracle.nlp_objective(go, po, co, x0[:, b], v)[:2], np.full(nPts, 0.7), jac=True,
+                       method="SLSQP", bounds=[(0.0, 1.0)] * nPts, options={"ftol": 1e-12, "maxiter": 500})
+        assert abs(J[b] - res.fun) < 2e-6 * abs(res.fun)
+        s = r["soln_of"](b)
+        assert np.max(np.abs(s["v"] - res.x)) < 5e-3
+
+
+def test_dense_basis_kernels_large_batch(ocs, oracle):
+    # Chebyshev is a dense basis: at batch >= 16384 the register-resident kernels take over
+    import torch
+    t = oracle.RK4Integrator(oracle.linspace(0, 10, 101)).t
+    nB, nC, batch = 12, 2, 16384
+    cg, co = ocs.ChebyshevControl(t, nB, nC), oracle.ChebyshevControl(t, nB, nC)
+    rng = np.random.default_rng(5)
+    v = rng.normal(size=(nB, nC, batch))
+    d = rng.normal(size=(t.size, nC, batch))
+    dev = torch.device("cuda:0")
+    u = cg.compute_u_dev(torch.tensor(v, device=dev)).cpu().numpy()
+    dv = cg.compute_dJdv_dev(torch.tensor(d, device=dev)).cpu().numpy()
+    for b in (0, 8191, 16383):
+        vb = v[:, :, b].reshape(-1)                       # control index fastest within a basis function
+        assert relerr(u[:, :, b].T, co.compute_u(vb)) < 1e-13
+        assert relerr(dv[:, :, b].reshape(-1), co.compute_dJdv(d[:, :, b].T)) < 1e-12
