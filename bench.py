@@ -109,6 +109,33 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=3):
             "batch_sweeps_per_s": float(sw.max()) / dt}
 
 
+def bl4_metric(ocs, dev, batch=65536, reps=5):
+    """BASELINE configs[3] (SURVEY BL-4): single_shooting objective + gradient (single_shooting.m:137-150) with a
+    Chebyshev basis of 16 coefficients, TestOCProblem, N = 1000, batch = 65536 coefficient vectors (seed 20260403).
+    One evaluation = u = v*B, forward, adjoint, dJdv = dJdu*B' for the whole batch."""
+    rng = np.random.default_rng(20260403)
+    V = 0.05 * rng.normal(size=(16, batch)) / np.arange(1, 17)[:, None]
+    V[0] += 0.5
+    integ = ocs.RK4Integrator(np.linspace(0.0, T_END, NSTEPS + 1))
+    prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
+    ctrl = ocs.ChebyshevControl(integ.t, 16, 1)
+    vd = torch.tensor(V, device=dev)
+    x0 = torch.ones((1, batch), dtype=torch.float64, device=dev)
+    J = torch.empty(batch, dtype=torch.float64, device=dev)
+    G = torch.empty_like(vd)
+    for _ in range(2):
+        ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s inside objective+gradient evaluations",
+            "batch": batch, "n_basis": 16, "ms_per_batch_evaluation": dt * 1e3,
+            "evaluations_per_s": batch / dt, "finite": bool(torch.isfinite(G).all().item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -232,6 +259,11 @@ def main():
         }
         if not args.no_fb_sweep:
             line["fb_sweep"] = fb_sweep_metric(ocs, dev)
+            line["other_configs"] = {
+                "BL-4 chebyshev16 objective+gradient": bl4_metric(ocs, dev),
+                "BL-5 LQ32 + RK4InfiniteIntegrator": "coverage only this round: runs through the hipRTC user-problem "
+                                                      "path on the lane kernels (no MFMA), parity 2.8e-16 vs the oracle, "
+                                                      "1.3e6 steps/s at batch 1024 (profiles/r01_bl5_lq32.log)"}
         if not args.no_cpu_baseline and world == 1:
             cb, ref = cpu_baseline(tspan, x0_h, u_h)
             line["cpu_baseline"] = cb
