@@ -136,6 +136,58 @@ def bl4_metric(ocs, dev, batch=65536, reps=5):
             "evaluations_per_s": batch / dt, "finite": bool(torch.isfinite(G).all().item())}
 
 
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (= fp64 vector peak), public spec
+
+
+def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2):
+    """BASELINE configs[4] (SURVEY BL-5): build-defined LQ32 (nS = 32, nC = 4, A = -diag(logspace(0,3,32)) + 0.1 G,
+    seed 20260405), RK4InfiniteIntegrator with N2 = N = 4000 tail steps (|lambda_max| h = 2.5), uStar = 0,
+    batch 8192 per GPU, full output.  The stage products A*Y / A'*k run on v_mfma_f64_16x16x4_f64
+    (csrc/ocs_lq_kernels.hip); fp64-compute-bound, so the roofline is the fp64 matrix peak."""
+    nS, nC, T = 32, 4, 10.0
+    rng = np.random.default_rng(20260405)
+    A = -np.diag(np.logspace(0, 3, nS)) + 0.1 * rng.normal(size=(nS, nS))
+    Bu = rng.normal(size=(nS, nC))
+    q, rd = rng.uniform(0.5, 1.5, nS), rng.uniform(1, 2, nC)
+    prob = ocs.LQProblem(A, Bu, q, rd, 0.05, [[-1.0, 1.0]] * nC)
+    N = nsteps
+    integ = ocs.RK4InfiniteIntegrator(np.linspace(0, T, N + 1), np.linspace(T, 2 * T, N + 1), np.zeros(nC))
+    g = torch.Generator(device=dev).manual_seed(20260405)
+    u = torch.rand((2 * N + 1, nC, batch), dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    x0 = torch.randn((nS, batch), dtype=torch.float64, device=dev, generator=g)
+    x = torch.empty((N + 1, nS + 1, batch), dtype=torch.float64, device=dev)
+    lam = torch.empty_like(x)
+    dJdu = torch.empty_like(u)
+    _, J = integ.compute_states_dev(prob, x0, u, x)
+    integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+    torch.cuda.synchronize()
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+    tf = tb = 0.0
+    for _ in range(reps):
+        ev[0].record()
+        integ.compute_states_dev(prob, x0, u, x, J)
+        ev[1].record()
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+        ev[2].record()
+        torch.cuda.synchronize()
+        tf += ev[0].elapsed_time(ev[1]) * 1e-3 / reps
+        tb += ev[1].elapsed_time(ev[2]) * 1e-3 / reps
+    steps = batch * 2 * N                    # RK4 steps of both legs (main + tail)
+    # algorithmic flops per (trajectory, step): 4 F + 3 recomputed F + 4 A'k products of 2 nS^2, the Bu u / Bu' k
+    # products, O(nS) axpys not counted (SURVEY 8(d): 12 mat-vecs, here 11 because F4 is not needed in the adjoint)
+    fl_fwd = 4 * 2 * nS * nS + 3 * 2 * nS * nC
+    fl_bwd = 7 * 2 * nS * nS + 2 * 2 * nS * nC + 2 * 2 * nS * nC
+    tfl_b = steps * fl_bwd / tb / 1e12
+    return {"value": steps / (tf + tb), "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
+            "batch": batch, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3, "ms_adjoint": tb * 1e3,
+            "roofline": {"bound": "mfma", "kernel": "k_lq_backward<2> (adjoint + dJdu, both legs)",
+                         "achieved": tfl_b, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": tfl_b / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "algorithmic_flops_per_trajectory_step": fl_bwd},
+            "pass_pair_TFLOPs": steps * (fl_fwd + fl_bwd) / (tf + tb) / 1e12,
+            "finite": bool(torch.isfinite(lam[0]).all().item()) and bool(torch.isfinite(J).all().item())}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -261,9 +313,7 @@ def main():
             line["fb_sweep"] = fb_sweep_metric(ocs, dev)
             line["other_configs"] = {
                 "BL-4 chebyshev16 objective+gradient": bl4_metric(ocs, dev),
-                "BL-5 LQ32 + RK4InfiniteIntegrator": "coverage only this round: runs through the hipRTC user-problem "
-                                                      "path on the lane kernels (no MFMA), parity 2.8e-16 vs the oracle, "
-                                                      "1.3e6 steps/s at batch 1024 (profiles/r01_bl5_lq32.log)"}
+                "BL-5 LQ32 + RK4InfiniteIntegrator (matrix cores)": bl5_metric(ocs, dev)}
         if not args.no_cpu_baseline and world == 1:
             cb, ref = cpu_baseline(tspan, x0_h, u_h)
             line["cpu_baseline"] = cb

@@ -45,6 +45,7 @@ extern "C" {
 /* ---- problem registry (device functors; see csrc/ocs_problems.hpp) ---- */
 #define OCS_PROBLEM_TEST 1     /* tests/TestOCProblem.m:22-38        params [c m r], nS=1, nC=1 */
 #define OCS_PROBLEM_LOGISTIC 2 /* LogisticK       params [c r m_1..m_nS], nC=1 */
+#define OCS_PROBLEM_LQ 3       /* linear-quadratic, shared Jacobian  params [r | A | Bu | q | rdiag], nS<=32, nC<=4 */
 #define OCS_PROBLEM_USER 100   /* plugin methods given as device source (ocs_problem_create_from_source) */
 
 /* ---- control parametrisations ---- */

@@ -7,7 +7,7 @@ The directory name is not a Python identifier; load it with
 """
 from . import _lib  # noqa: F401  fails loudly when libocs.so is missing
 from ._lib import OcsError  # noqa: F401
-from .problem import OCProblem, TestOCProblem, LogisticProblem, UserProblem  # noqa: F401
+from .problem import OCProblem, TestOCProblem, LogisticProblem, LQProblem, UserProblem  # noqa: F401
 from .integrator import Integrator, RK4Integrator, RK4InfiniteIntegrator  # noqa: F401
 from .control import Control, PWLinearControl, PWConstantControl, ChebyshevControl  # noqa: F401
 from .interp import vectorInterpolant, heval  # noqa: F401

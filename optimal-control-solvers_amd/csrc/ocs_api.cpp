@@ -61,6 +61,16 @@ int ocs_problem_create(ocs_problem* out, int problem_id, int nS, int nC, const d
     p->par.assign(params, params + nparams);
     p->user2func.resize(nparams);
     for (int k = 0; k < nparams; ++k) p->user2func[k] = k;
+  } else if (problem_id == OCS_PROBLEM_LQ) {
+    // build-defined linear-quadratic problem: params [r | A | Bu | q | rdiag]
+    if (nS < 1 || nC < 1 || nparams != 1 + nS * nS + nS * nC + nS + nC) {
+      delete p;
+      return fail(OCS_ERR_SHAPE, "LQ needs params [r | A (nS x nS) | Bu (nS x nC) | q (nS) | rdiag (nC)]");
+    }
+    p->functor = Functor::LQ;
+    p->par.assign(params, params + nparams);
+    p->user2func.resize(nparams);
+    for (int k = 0; k < nparams; ++k) p->user2func[k] = k;
   } else {
     delete p;
     return fail(OCS_ERR_UNSUPPORTED, "unknown problem id %d", problem_id);

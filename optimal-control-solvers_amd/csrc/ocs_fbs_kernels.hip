@@ -50,6 +50,7 @@ int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const dou
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_COSTATE, dim3((batch + 63) / 64), dim3(64), args, s);
   }
+  if (p.functor != Functor::Logistic) return -1;
   OCS_DISPATCH_LOGISTIC2(p.nS, run_costate<P>(a, s));
   return hip_rc3(hipGetLastError());
 }
@@ -66,6 +67,7 @@ int launch_control_grid(const ProblemDesc& p, const GridDesc& g, int batch, cons
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, 2 * g.N + 1), dim3(256), args, s);
   }
+  if (p.functor != Functor::Logistic) return -1;
   OCS_DISPATCH_LOGISTIC2(p.nS, run_control_grid<P>(a, s));
   return hip_rc3(hipGetLastError());
 }
@@ -85,6 +87,7 @@ int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const i
     return jit_launch(p.user, UK_CONTROL_PTS, dim3((batch + 255) / 256, (nq + kPtsPerThread - 1) / kPtsPerThread),
                       dim3(256), args, s);
   }
+  if (p.functor != Functor::Logistic) return -1;
   OCS_DISPATCH_LOGISTIC2(p.nS, run_control_pts<P>(a, s));
   return hip_rc3(hipGetLastError());
 }
@@ -99,6 +102,7 @@ int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hi
     void* args[] = {&nq, &tq, &ps, &TUQ};
     return jit_launch(p.user, UK_TU_AT, dim3((nq + 255) / 256), dim3(256), args, s);
   }
+  if (p.functor != Functor::Logistic) return -1;
   OCS_DISPATCH_LOGISTIC2(p.nS, run_tu_at<P>(nq, tq, p.ps, TUQ, s));
   return hip_rc3(hipGetLastError());
 }

@@ -7,7 +7,7 @@
 namespace ocs {
 
 // Which device functor a problem handle resolves to.
-enum class Functor : int { Logistic = 1, User = 100 };
+enum class Functor : int { Logistic = 1, LQ = 3, User = 100 };
 struct UserModule;  // hipRTC-compiled user problem (ocs_jit.hpp)
 
 struct ProblemDesc {
@@ -48,6 +48,18 @@ int launch_forward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const 
                       double* x, double* J, hipStream_t s);
 int launch_backward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                        const double* lamT, double* lam, double* dJdu, double* lam0, hipStream_t s);
+
+struct FwdOpts;
+struct BwdOpts;
+// matrix-core kernels of the shared-Jacobian linear-quadratic problem (ocs_lq_kernels.hip)
+bool lq_supported(int nS, int nC);
+int launch_tcoef_lq(const ProblemDesc& p, const GridDesc& g, hipStream_t s);
+int launch_forward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
+                      double* x, double* J, const FwdOpts& o, hipStream_t s);
+int launch_backward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                       const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s);
+int launch_eval_lq(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
+                   const double* v, double* out, hipStream_t s);
 
 struct FwdOpts {
   int mapping = MAP_AUTO;

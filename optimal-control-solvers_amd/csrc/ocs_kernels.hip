@@ -75,24 +75,26 @@ __global__ void k_count_nonfinite(const double* __restrict__ v, int n, int* __re
 
 bool functor_supported(Functor f, int nS, int nC) {
   if (f == Functor::User) return true;
+  if (f == Functor::LQ) return lq_supported(nS, nC);
   if (f == Functor::Logistic) return nS >= 1 && nS <= 4 && nC == 1;
   return false;
 }
 int functor_ntc(Functor f, int nS) {
   (void)nS;
-  if (f == Functor::User) return 1;
+  if (f == Functor::User || f == Functor::LQ) return 1;
   if (f == Functor::Logistic) return LogisticK<1>::NTC;
   return 0;
 }
 int functor_ntu(Functor f, int nS) {
   (void)nS;
-  if (f == Functor::User) return 1;
+  if (f == Functor::User || f == Functor::LQ) return 1;
   if (f == Functor::Logistic) return LogisticK<1>::NTU;
   return 0;
 }
 unsigned functor_tc_param_mask(Functor f, int nS) {
   (void)nS;
   if (f == Functor::User) return 0u;
+  if (f == Functor::LQ) return 1u;  // r feeds the e^{-rt} table
   if (f == Functor::Logistic) return LogisticK<1>::TC_PARAM_MASK;
   return 0;
 }
@@ -115,6 +117,7 @@ int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
     void* a2[] = {&N, &HT, &TCc, &REC};
     return jit_launch(p.user, UK_BUILD_REC, dim3((N + 2 * kRecPad + 255) / 256), dim3(256), a2, s);
   }
+  if (p.functor == Functor::LQ) return launch_tcoef_lq(p, g, s);
   OCS_DISPATCH_LOGISTIC(p.nS, run_tcoef<P>(p, g, s));
   return hip_rc(hipGetLastError());
 }
@@ -158,6 +161,7 @@ static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested,
 
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
+  if (p.functor == Functor::LQ) return launch_forward_lq(p, g, batch, x0, u, x, J, o, s);
   const bool plain = !o.uconst && !o.Jadd && !o.usel;
   const int map = choose_mapping(p, g.N, batch, o.mapping, plain, false);
   if (map == MAP_PIPELINE) {
@@ -193,6 +197,7 @@ static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
 }
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
+  if (p.functor == Functor::LQ) return launch_backward_lq(p, g, batch, xck, u, lamT, lam, dJdu, o, s);
   const bool plain = !o.uconst && !o.usel;
   const int map = choose_mapping(p, g.N, batch, o.mapping, plain, true);
   if (map == MAP_PIPELINE) {
@@ -226,6 +231,7 @@ int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const d
     void* args[] = {&which, &k, &t, &y, &u, &v, &ps, &out};
     return jit_launch(p.user, UK_EVAL, dim3((k + 127) / 128), dim3(128), args, s);
   }
+  if (p.functor == Functor::LQ) return launch_eval_lq(p, which, k, t, y, u, v, out, s);
   OCS_DISPATCH_LOGISTIC(p.nS, run_eval<P>(p, which, k, t, y, u, v, out, s));
   return hip_rc(hipGetLastError());
 }

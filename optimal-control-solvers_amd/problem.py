@@ -13,7 +13,7 @@ import numpy as np
 from . import _lib
 from ._lib import check, dp, lib
 
-PROBLEM_TEST, PROBLEM_LOGISTIC = 1, 2
+PROBLEM_TEST, PROBLEM_LOGISTIC, PROBLEM_LQ = 1, 2, 3
 
 
 def _f(a, shape=None):
@@ -125,3 +125,20 @@ class LogisticProblem(OCProblem):
         m = np.atleast_1d(np.asarray(m, dtype=np.float64))
         self.c, self.m, self.r = float(c), m, float(r)
         super().__init__(PROBLEM_LOGISTIC, m.size, 1, np.concatenate([[c, r], m]), ControlBounds)
+
+
+class LQProblem(OCProblem):
+    """Build-defined linear-quadratic problem: F = [A x + Bu u ; e^{-rt}(x'diag(q)x + u'diag(rdiag)u)].
+    The Jacobian A is shared by the whole batch, so the integrator passes run on the matrix cores
+    (csrc/ocs_lq_kernels.hip).  nS <= 32, nC <= 4."""
+
+    def __init__(self, A, Bu, q, rdiag, r, ControlBounds):
+        A = np.asarray(A, dtype=np.float64)
+        nS = A.shape[0]
+        Bu = np.asarray(Bu, dtype=np.float64).reshape(nS, -1)
+        nC = Bu.shape[1]
+        self.A, self.Bu, self.r = A, Bu, float(r)
+        self.q = np.asarray(q, dtype=np.float64).reshape(nS)
+        self.rdiag = np.asarray(rdiag, dtype=np.float64).reshape(nC)
+        par = np.concatenate([[float(r)], A.ravel(order="F"), Bu.ravel(order="F"), self.q, self.rdiag])
+        super().__init__(PROBLEM_LQ, nS, nC, par, ControlBounds)
