@@ -21,6 +21,10 @@
 #include "ocs_device_common.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_rk4_kernels.hpp"
+#ifdef OCS_LQ_STAMPS
+#include <cstdio>
+#include <vector>
+#endif
 
 namespace ocs {
 
@@ -59,6 +63,7 @@ struct LQArgs {
   double* lam;          // [N+1][nAug][B] or null
   double* dJdu;         // [2N+1][nC][B] or null
   double* lam0;         // [nAug][B] or null
+  long long* dbg;       // diagnostic builds only: [blocks][8] cycle sums
 };
 
 // D = A(16x4) * B(4x16) + C on one wave; a: lane (g,i) holds A[i][g]; b: lane (g,n) holds B[g][n];
@@ -114,6 +119,15 @@ __device__ static inline void unpack(const d4 (&acc)[RT], double (&f)[4 * RT]) {
     f[4 * rt + 2] = acc[rt].z;
     f[4 * rt + 3] = acc[rt].w;
   }
+}
+
+// Guarded accesses without divergent branches: a padded row / an unused control row reads a valid
+// address and the value is replaced by 0; stores take a uniform fast path when nothing is padded.
+// (exec-masked branches around every access would split the step into many basic blocks: the waitcnt
+// pass then cannot count the loads in flight and the matrix products get moved across the exchanges.)
+__device__ static inline double ld_sel(const double* base, size_t off, bool ok) {
+  const double v = base[ok ? off : 0];
+  return ok ? v : 0.0;
 }
 
 // sum over the four lanes (g = 0..3) that share a trajectory
@@ -191,11 +205,17 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
   for (int m = 0; m < KS; ++m) y[m] = (4 * m + g < nS) ? a.x0[(size_t)(4 * m + g) * B + b] : 0.0;
 
   double* xo = a.x + (size_t)g * B + b;
+  const bool full = nS == 16 * RT;
   auto store_x = [&]() OCS_INLINE {
     if (!OUT_X) return;
+    if (full) {
 #pragma unroll
-    for (int m = 0; m < KS; ++m)
-      if (4 * m + g < nS) xo[(size_t)(4 * m) * B] = y[m];
+      for (int m = 0; m < KS; ++m) xo[(size_t)(4 * m) * B] = y[m];
+    } else {
+#pragma unroll
+      for (int m = 0; m < KS; ++m)
+        if (4 * m + g < nS) xo[(size_t)(4 * m) * B] = y[m];
+    }
     if (g == 0) xo[(size_t)nS * B] = yc;
     xo += nAugB;
   };
@@ -227,8 +247,9 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
     if (!UCONST) {
       const int in = i + 1 < N ? i + 1 : i;
       const double* q = up + (size_t)(2 * in) * ustride;
-      uMn = uact ? q[ustride] : 0.0;
-      uBn = uact ? q[2 * ustride] : 0.0;
+      const double vM = q[ustride], vB = q[2 * ustride];  // unused control rows read row 0 and are zeroed
+      uMn = uact ? vM : 0.0;
+      uBn = uact ? vB : 0.0;
       P.bu_times(uM, buM);
       P.bu_times(uB, buB);
     }
@@ -316,11 +337,17 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
   lamc = a.lamT ? a.lamT[(size_t)nS * B + b] : 1.0;
 
   double* lo = a.lam + (size_t)N * nAugB + (size_t)g * B + b;
+  const bool full = nS == 16 * RT;
   auto store_lam = [&]() OCS_INLINE {
     if (!OUT_LAM) return;
+    if (full) {
 #pragma unroll
-    for (int m = 0; m < KS; ++m)
-      if (4 * m + g < nS) lo[(size_t)(4 * m) * B] = lam[m];
+      for (int m = 0; m < KS; ++m) lo[(size_t)(4 * m) * B] = lam[m];
+    } else {
+#pragma unroll
+      for (int m = 0; m < KS; ++m)
+        if (4 * m + g < nS) lo[(size_t)(4 * m) * B] = lam[m];
+    }
     if (g == 0) lo[(size_t)nS * B] = lamc;
     lo -= nAugB;
   };
@@ -359,14 +386,15 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
     recp -= rec_stride(1);
     const Rec nxt = load_rec<1>(recp);  // the table is padded before step 0
     const int ip = i > 0 ? i - 1 : 0;
-    const double* cq = a.xck + (size_t)ip * nAugB + (size_t)g * B + b;
+    const double* cq = a.xck + (size_t)ip * nAugB + b;
     double yn[KS];
 #pragma unroll
-    for (int m = 0; m < KS; ++m) yn[m] = (4 * m + g < nS) ? cq[(size_t)(4 * m) * B] : 0.0;
+    for (int m = 0; m < KS; ++m) yn[m] = ld_sel(cq, (size_t)(4 * m + g) * B, 4 * m + g < nS);
     double uAn = uA, uMn = uM;
     if (!UCONST) {
-      uAn = uact ? up[(size_t)(2 * ip) * ustride] : 0.0;
-      uMn = uact ? up[(size_t)(2 * ip + 1) * ustride] : 0.0;
+      const double vA = up[(size_t)(2 * ip) * ustride], vM = up[(size_t)(2 * ip + 1) * ustride];
+      uAn = uact ? vA : 0.0;
+      uMn = uact ? vM : 0.0;
       P.bu_times(uA, buA);
       P.bu_times(uM, buM);
     }
@@ -440,6 +468,537 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Mapping "M2": two waves per 16 trajectories (17 <= nS <= 32)
+// ---------------------------------------------------------------------------------------
+// With one wave per 16 trajectories a batch of 8192 occupies 512 of the 1024 SIMDs.  Here a pair of waves
+// shares 16 trajectories (a 256-thread workgroup holds two independent pairs, so that one workgroup
+// spreads over the four SIMDs of a CU: two 128-thread workgroups on a CU were observed to share
+// SIMDs 0 and 1).  Wave w of a pair owns row tile w of every product: its accumulator holds rows 16w + g + 4j, it
+// keeps only its half of the stage state up to date and receives the partner's half through LDS
+// (4 doubles per lane per stage, two ping-pong slots, one s_barrier per exchange).  The k-steps that
+// multiply the wave's own half are issued between posting it and fetching the partner's, so the LDS
+// round trip runs under matrix-core work.  The adjoint needs the partner's half of Y2, Y3 (recompute)
+// and of k3, k2, k1, lam; A'k's elementwise term 2 e^{-rt} (q .* Y) k_last and the Bu'k products only
+// touch own rows (the latter are K-split: each wave contracts its 16 rows, wave 0 adds the two parts).
+typedef double d2 __attribute__((ext_vector_type(2)));
+constexpr int kX2Pair = 64, kX2Wave = 3 * kX2Pair, kX2Slot = 2 * kX2Wave;  // d2 units
+
+__device__ static inline void lq_lds_barrier() {
+  __builtin_amdgcn_sched_barrier(0);
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+struct LQ2Pending {
+  d2 a, b, c;
+};
+// diagnostic build (-DOCS_LQ_STAMPS): cycle stamps around the phases of an exchange, summed per wave
+#ifdef OCS_LQ_STAMPS
+#define LQ_T() __builtin_amdgcn_s_memtime()
+#else
+#define LQ_T() 0LL
+#endif
+struct LQ2X {
+  d2* mine;
+  const d2* theirs;
+  int tog;
+  long long ts[4] = {0, 0, 0, 0};  // post->barrier passed | ->own half issued | ->partner's values here | ->result read
+  __device__ inline void init(d2* xb, int w, int lane) {
+    mine = xb + w * kX2Wave + lane;
+    theirs = xb + (1 - w) * kX2Wave + lane;
+    tog = 0;
+  }
+  // An exchange is three calls with matrix-core work in between, so that the LDS round trip never has the
+  // matrix pipe idle: post (ds_write) -> [first product of the own half] -> sync (barrier + ds_read issue)
+  // -> [rest of the own half, any independent vector work] -> take (the partner's values).
+  template <bool EXTRA>
+  __device__ inline void post(const double (&own)[4], double e0 = 0.0, double e1 = 0.0) {
+    d2* p = mine + tog;
+    p[0] = d2{own[0], own[1]};
+    p[kX2Pair] = d2{own[2], own[3]};
+    if (EXTRA) p[2 * kX2Pair] = d2{e0, e1};
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  template <bool EXTRA>
+  __device__ inline LQ2Pending sync() {
+    lq_lds_barrier();
+    const d2* p = theirs + tog;
+    LQ2Pending r;
+    r.a = p[0];
+    r.b = p[kX2Pair];
+    r.c = EXTRA ? p[2 * kX2Pair] : d2{0.0, 0.0};
+    tog = kX2Slot - tog;
+    __builtin_amdgcn_sched_barrier(0);
+    return r;
+  }
+  __device__ static inline void take(const LQ2Pending& r, double (&oth)[4]) {
+    oth[0] = r.a.x; oth[1] = r.a.y; oth[2] = r.b.x; oth[3] = r.b.y;
+  }
+};
+
+// product of this wave's row tile with a vector whose own half is known and whose other half arrives
+// through the exchange; `mid` is independent work placed behind the own half
+template <bool EXTRA, class Mid>
+__device__ static inline LQ2Pending xmv(LQ2X& X, const double (&Fo)[4], const double (&Fx)[4], const double (&vo)[4],
+                                        d4 init, double (&vx)[4], double (&f)[4], double e0, double e1, Mid&& mid) {
+  const d4 z = {0.0, 0.0, 0.0, 0.0};
+  const long long t0 = LQ_T();
+  X.post<EXTRA>(vo, e0, e1);
+  // two products ahead of the barrier: the wave blocks on the second until the first has left the pipe
+  // (~70 cycles), which is about when its LDS writes have landed; the other two cover the read latency
+  d4 acc = mma(Fo[0], vo[0], init);
+  d4 alt = mma(Fo[1], vo[1], z);
+  const LQ2Pending r = X.sync<EXTRA>();
+  const long long t1 = LQ_T();
+  acc = mma(Fo[2], vo[2], acc);
+  alt = mma(Fo[3], vo[3], alt);
+  mid();
+#ifdef OCS_LQ_STAMPS
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  const long long t2 = LQ_T();
+  LQ2X::take(r, vx);
+#ifdef OCS_LQ_STAMPS
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+  const long long t3 = LQ_T();
+  acc = mma(Fx[0], vx[0], acc);
+  alt = mma(Fx[1], vx[1], alt);
+  acc = mma(Fx[2], vx[2], acc);
+  alt = mma(Fx[3], vx[3], alt);
+  acc += alt;
+  f[0] = acc.x; f[1] = acc.y; f[2] = acc.z; f[3] = acc.w;
+#ifndef OCS_LQ_STAMPS
+  // Issue order of this region (from the barrier to the next post): one matrix instruction, then a few of the
+  // independent vector / memory instructions (`mid`, address arithmetic, the step's loads and stores), and so
+  // on.  A wave issues in order and blocks on a matrix instruction while the pipe is busy (~70 cycles), so
+  // independent work placed BEHIND the last product would run with the pipe idle.
+#pragma unroll
+  for (int k = 0; k < 6; ++k) {
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
+    __builtin_amdgcn_sched_group_barrier(0x060, 2, 0);  // VMEM read / write
+  }
+#endif
+#ifdef OCS_LQ_STAMPS
+  asm volatile("" ::"v"(f[0]), "v"(f[1]), "v"(f[2]), "v"(f[3]));
+  __builtin_amdgcn_sched_barrier(0);
+  const long long t4 = LQ_T();
+  X.ts[0] += t1 - t0;
+  X.ts[1] += t2 - t1;
+  X.ts[2] += t3 - t2;
+  X.ts[3] += t4 - t3;
+#endif
+  return r;
+}
+// the same product when both halves are already known (no exchange)
+__device__ static inline void mv2(const double (&Fo)[4], const double (&Fx)[4], const double (&vo)[4],
+                                  const double (&vx)[4], d4 init, double (&f)[4]) {
+  const d4 z = {0.0, 0.0, 0.0, 0.0};
+  d4 acc = mma(Fo[0], vo[0], init);
+  d4 alt = mma(Fo[1], vo[1], z);
+  acc = mma(Fo[2], vo[2], acc);
+  alt = mma(Fo[3], vo[3], alt);
+  acc = mma(Fx[0], vx[0], acc);
+  alt = mma(Fx[1], vx[1], alt);
+  acc = mma(Fx[2], vx[2], acc);
+  alt = mma(Fx[3], vx[3], alt);
+  acc += alt;
+  f[0] = acc.x; f[1] = acc.y; f[2] = acc.z; f[3] = acc.w;
+}
+
+struct LQ2Core {
+  double Ao[4], Ax[4];  // fragments of A, row tile w: own k-steps (kk = 4w + j) and the partner's (kk = 4(1-w) + j)
+  double Bu;            // fragment of Bu, row tile w
+  double q[4];          // q[16w + 4j + g]
+  double R;             // rdiag[g] on wave 0, 0 on wave 1 (each control's cost is counted once)
+  __device__ inline void load(const double* ps, int nS, int nC, int w, int g, int i) {
+    const double* A = ps + 1;
+    const int r = 16 * w + i;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = 4 * (4 * w + j) + g, cx = 4 * (4 * (1 - w) + j) + g;
+      Ao[j] = (r < nS && co < nS) ? A[r + (size_t)nS * co] : 0.0;
+      Ax[j] = (r < nS && cx < nS) ? A[r + (size_t)nS * cx] : 0.0;
+    }
+    const double* bu = A + (size_t)nS * nS;
+    Bu = (r < nS && g < nC) ? bu[r + (size_t)nS * g] : 0.0;
+    const double* qq = bu + (size_t)nS * nC;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) q[j] = (16 * w + 4 * j + g < nS) ? qq[16 * w + 4 * j + g] : 0.0;
+    R = (w == 0 && g < nC) ? qq[nS + g] : 0.0;
+  }
+  __device__ inline d4 bu_times(double u) const {
+    const d4 z = {0.0, 0.0, 0.0, 0.0};
+    return mma(Bu, u, z);
+  }
+  __device__ inline double cost_part(const double (&Yo)[4], double u, double e) const {
+    double s = R * (u * u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s = __builtin_fma(q[j], Yo[j] * Yo[j], s);
+    return e * s;
+  }
+};
+
+template <bool FULL, bool OUT_X, bool UCONST>
+__global__ __launch_bounds__(256) void k_lq2_forward(const LQArgs a) {
+  using Rec = StepRec<1>;
+  __shared__ d2 xb2[2][2 * kX2Slot];
+  const int pair = threadIdx.x >> 7, w = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+  d2* xb = xb2[pair];
+  const int b0 = (blockIdx.x * 2 + pair) * 16 + n;
+  const int b = b0 < a.batch ? b0 : a.batch - 1;
+  const size_t B = (size_t)a.batch;
+  const int nS = a.nS, nC = a.nC, N = a.N;
+  const size_t nAugB = (size_t)(nS + 1) * B;
+  LQ2X X;
+  X.init(xb, w, lane);
+  LQ2Core P;
+  P.load(a.ps, nS, nC, w, g, n);
+
+  // own rows 16w + 4j + g, partner rows 16(1-w) + 4j + g
+  double yo[4], yx[4], yc = 0.0;  // yc: this wave's share of the running cost
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ro = 16 * w + 4 * j + g, rx = 16 * (1 - w) + 4 * j + g;
+    yo[j] = ro < nS ? a.x0[(size_t)ro * B + b] : 0.0;
+    yx[j] = rx < nS ? a.x0[(size_t)rx * B + b] : 0.0;
+  }
+  double* xo = a.x + (size_t)(16 * w + g) * B + b;
+  if (OUT_X) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (16 * w + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = yo[j];
+  }
+
+  const bool uact = g < nC;
+  const size_t ustride = (size_t)nC * B;
+  const double* up = a.u + (size_t)(uact ? g : 0) * B + b;
+  double uA = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? *up : 0.0);
+  double uM = uA, uB = uA;
+  if (!UCONST) {
+    uM = uact ? up[ustride] : 0.0;
+    uB = uact ? up[2 * ustride] : 0.0;
+  }
+  d4 buA = P.bu_times(uA), buM = buA, buB = buA;
+  double F1[4];
+  mv2(P.Ao, P.Ax, yo, yx, buA, F1);  // stage 1 of step 0 (later steps: under the y exchange of the step before)
+  double* xc = a.x + (size_t)nS * B + b;  // cost row of x, written one exchange late by wave 0 (see below)
+  auto nothing = []() {};
+
+  // Per-step inputs (uniform record, two control samples) are requested TWO steps ahead into two slots that the
+  // steps use alternately.  vmcnt counts loads and stores in order, so with a lead of one step the wait for
+  // step i+1's inputs would also be a wait for the stores of step i; the loop is unrolled by the two slots (and
+  // the odd last step peeled) so that no register copy of a freshly requested value and no branch sits in a step.
+  struct Slot {
+    Rec r;
+    double uM, uB;  // raw loads; unused control rows are zeroed when the slot is consumed
+  };
+  auto request = [&](int i, Slot& q) OCS_INLINE {
+    q.r = load_rec<1>(a.REC + (size_t)i * rec_stride(1));  // the table is padded past step N-1
+    if (!UCONST) {
+      const int ic = i < N ? i : N - 1;
+      const double* pu = up + (size_t)(2 * ic) * ustride;
+      q.uM = pu[ustride];
+      q.uB = pu[2 * ustride];
+    }
+  };
+  auto step = [&](int i, Slot& q) OCS_INLINE {
+    const Rec cur = q.r;
+    if (!UCONST) {
+      uM = uact ? q.uM : 0.0;
+      uB = uact ? q.uB : 0.0;
+    }
+    request(i + 2, q);
+    if (!UCONST) {
+      buM = P.bu_times(uM);
+      buB = P.bu_times(uB);
+    }
+    double F2[4], F3[4], F4[4], Yo[4], Yx[4];
+    double cs = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Yo[j] = __builtin_fma(cur.hh, F1[j], yo[j]);  // :40
+    // this exchange also carries the wave's share of the running cost up to x(:, i) (reduced over g under
+    // the previous exchange); wave 0 then completes the cost row of column i
+    const LQ2Pending r2 = xmv<true>(X, P.Ao, P.Ax, Yo, buM, Yx, F2, yc, 0.0, [&]() OCS_INLINE {   // :41
+      cs = P.cost_part(yo, uA, cur.tcA[0]) + 2.0 * P.cost_part(Yo, uM, cur.tcM[0]);
+    });
+    const double ctot = yc + r2.c.x;  // x(end, i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Yo[j] = __builtin_fma(cur.hh, F2[j], yo[j]);  // :44
+    xmv<false>(X, P.Ao, P.Ax, Yo, buM, Yx, F3, 0.0, 0.0, [&]() OCS_INLINE {                       // :45
+      cs += 2.0 * P.cost_part(Yo, uM, cur.tcM[0]);
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Yo[j] = __builtin_fma(cur.h, F3[j], yo[j]);   // :48
+    xmv<false>(X, P.Ao, P.Ax, Yo, buB, Yx, F4, 0.0, 0.0, [&]() OCS_INLINE {                       // :49
+      cs += P.cost_part(Yo, uB, cur.tcB[0]);
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j)                                               // :50
+      yo[j] = __builtin_fma(cur.h6, (F1[j] + 2.0 * F2[j]) + (2.0 * F3[j] + F4[j]), yo[j]);
+    // y exchange; stage 1 of the next step is the product that runs under it
+    xmv<false>(X, P.Ao, P.Ax, yo, buB, yx, F1, 0.0, 0.0, [&]() OCS_INLINE {                       // :37
+      yc = __builtin_fma(cur.h6, sum_over_g(cs), yc);
+    });
+    if (OUT_X) {
+      if (w == 0 && g == 0) xc[(size_t)i * nAugB] = ctot;
+      xo += nAugB;
+      if (FULL) {  // nS == 32: no padded rows, the step stays one basic block
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xo[(size_t)(4 * j) * B] = yo[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (16 * w + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = yo[j];
+      }
+    }
+    uA = uB;
+    buA = buB;
+  };
+  Slot sa, sb;
+  request(0, sa);
+  request(1, sb);
+  int i = 0;
+  for (; i + 1 < N; i += 2) {
+    step(i, sa);
+    step(i + 1, sb);
+  }
+  if (i < N) step(i, sa);
+  {  // the partner's share of the final cost
+    X.post<true>(yo, yc, 0.0);
+    const LQ2Pending r = X.sync<true>();
+    if (w == 0 && g == 0) {
+      const double Jt = yc + r.c.x;
+      if (OUT_X) xc[(size_t)N * nAugB] = Jt;
+      a.J[b] = a.Jadd ? a.Jadd[b] + Jt : Jt;  // J = x(end,end)   :55
+    }
+  }
+#ifdef OCS_LQ_STAMPS
+  if (a.dbg && lane == 0 && pair == 0)
+    for (int k = 0; k < 4; ++k) a.dbg[blockIdx.x * 8 + w * 4 + k] = X.ts[k];
+#endif
+}
+
+template <bool FULL, bool OUT_LAM, bool OUT_DJDU, bool UCONST>
+__global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
+  using Rec = StepRec<1>;
+  __shared__ d2 xb2[2][2 * kX2Slot];
+  const int pair = threadIdx.x >> 7, w = (threadIdx.x >> 6) & 1, lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+  d2* xb = xb2[pair];
+  const int b0 = (blockIdx.x * 2 + pair) * 16 + n;
+  const int b = b0 < a.batch ? b0 : a.batch - 1;
+  const size_t B = (size_t)a.batch;
+  const int nS = a.nS, nC = a.nC, N = a.N;
+  const size_t nAugB = (size_t)(nS + 1) * B;
+  LQ2X X;
+  X.init(xb, w, lane);
+  LQ2Core P;
+  P.load(a.ps, nS, nC, w, g, n);
+  const double Rall = (g < nC) ? a.ps[1 + (size_t)nS * nS + (size_t)nS * nC + nS + g] : 0.0;
+  double ATo[4], ATx[4], BuT[4];  // fragments of A' (row tile w) and of Bu' restricted to this wave's rows
+  {
+    const double* A = a.ps + 1;
+    const double* bu = A + (size_t)nS * nS;
+    const int r = 16 * w + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int co = 4 * (4 * w + j) + g, cx = 4 * (4 * (1 - w) + j) + g;
+      ATo[j] = (r < nS && co < nS) ? A[co + (size_t)nS * r] : 0.0;
+      ATx[j] = (r < nS && cx < nS) ? A[cx + (size_t)nS * r] : 0.0;
+      BuT[j] = (co < nS && n < nC) ? bu[co + (size_t)nS * n] : 0.0;
+    }
+  }
+  // this wave's part of (Bu' v)_g: the contraction over its own 16 rows
+  auto but_part = [&](const double (&vo)[4]) OCS_INLINE {
+    const d4 z = {0.0, 0.0, 0.0, 0.0};
+    d4 acc = mma(BuT[0], vo[0], z), alt = mma(BuT[1], vo[1], z);
+    acc = mma(BuT[2], vo[2], acc);
+    alt = mma(BuT[3], vo[3], alt);
+    return acc.x + alt.x;
+  };
+  auto qy = [&](const double (&Yo)[4], double e2kl) OCS_INLINE {
+    return d4{P.q[0] * Yo[0] * e2kl, P.q[1] * Yo[1] * e2kl, P.q[2] * Yo[2] * e2kl, P.q[3] * Yo[3] * e2kl};
+  };
+
+  double lo_[4], lx_[4], lamc;  // lam own / partner rows
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ro = 16 * w + 4 * j + g, rx = 16 * (1 - w) + 4 * j + g;
+    lo_[j] = (a.lamT && ro < nS) ? a.lamT[(size_t)ro * B + b] : 0.0;
+    lx_[j] = (a.lamT && rx < nS) ? a.lamT[(size_t)rx * B + b] : 0.0;
+  }
+  lamc = a.lamT ? a.lamT[(size_t)nS * B + b] : 1.0;
+  double* lp = a.lam + (size_t)N * nAugB + (size_t)(16 * w + g) * B + b;
+  auto store_lam = [&]() OCS_INLINE {
+    if (!OUT_LAM) return;
+    if (FULL) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lp[(size_t)(4 * j) * B] = lo_[j];
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        if (16 * w + 4 * j + g < nS) lp[(size_t)(4 * j) * B] = lo_[j];
+    }
+    if (w == 0 && g == 0) lp[(size_t)nS * B] = lamc;
+    lp -= nAugB;
+  };
+  store_lam();
+
+  const bool uact = g < nC;
+  const size_t ustride = (size_t)nC * B;
+  const size_t uoff = (size_t)(uact ? g : 0) * B + b;
+  const double* up = a.u + uoff;
+  double* dq = a.dJdu + uoff;
+  double uB = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? up[(size_t)(2 * N) * ustride] : 0.0);
+  double uA = uB, uM = uB;
+  if (!UCONST) {
+    uA = uact ? up[(size_t)(2 * N - 2) * ustride] : 0.0;
+    uM = uact ? up[(size_t)(2 * N - 1) * ustride] : 0.0;
+  }
+  d4 buA = P.bu_times(uA), buM = P.bu_times(uM);
+  double k1co[4] = {0.0, 0.0, 0.0, 0.0}, k1lc = 0.0;
+
+  auto load_ck = [&](int i, double (&o)[4], double (&x)[4]) OCS_INLINE {
+    const double* c = a.xck + (size_t)i * nAugB + b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int ro = 16 * w + 4 * j + g, rx = 16 * (1 - w) + 4 * j + g;
+      o[j] = FULL ? c[(size_t)ro * B] : ld_sel(c, (size_t)ro * B, ro < nS);
+      x[j] = FULL ? c[(size_t)rx * B] : ld_sel(c, (size_t)rx * B, rx < nS);
+    }
+  };
+  // Per-step inputs (uniform record, checkpoint y_i, two control samples) are requested two steps ahead into
+  // two alternating slots, as in the forward pass (k_lq2_forward explains why).
+  struct Slot {
+    Rec r;
+    double yo[4], yx[4];
+    double uA, uM;  // raw loads
+  };
+  auto request = [&](int i, Slot& q) OCS_INLINE {
+    q.r = load_rec<1>(a.REC + (long long)i * rec_stride(1));  // the table is padded before step 0
+    const int ic = i > 0 ? i : 0;
+    load_ck(ic, q.yo, q.yx);
+    if (!UCONST) {
+      q.uA = up[(size_t)(2 * ic) * ustride];
+      q.uM = up[(size_t)(2 * ic + 1) * ustride];
+    }
+  };
+  double yo[4], F[4];
+  double eA0 = 0.0;
+  auto nothing = []() {};
+
+  // step i reads its record and controls from `q`, then refills `q` for step i-2; `qn` holds step i-1, whose
+  // checkpoint is consumed at the end of this step (its first stage runs under the lam exchange)
+  auto step = [&](int i, Slot& q, Slot& qn) OCS_INLINE {
+    const Rec cur = q.r;
+    if (!UCONST) {
+      uA = uact ? q.uA : 0.0;
+      uM = uact ? q.uM : 0.0;
+    }
+    request(i - 2, q);
+    // recompute the stage states (same products as the forward pass); only F2 and F3 need the partner's half
+    double Y2o[4], Y3o[4], Y4o[4], Yx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y2o[j] = __builtin_fma(cur.hh, F[j], yo[j]);
+    xmv<false>(X, P.Ao, P.Ax, Y2o, buM, Yx, F, 0.0, 0.0, nothing);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y3o[j] = __builtin_fma(cur.hh, F[j], yo[j]);
+    xmv<false>(X, P.Ao, P.Ax, Y3o, buM, Yx, F, 0.0, 0.0, nothing);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y4o[j] = __builtin_fma(cur.h, F[j], yo[j]);
+
+    const double k4l = cur.h6 * lamc, k3l = cur.h3 * lamc, k2l = k3l, k1l = k4l;
+    double k4o[4], k4x[4], k3o[4], k2o[4], k1o[4], kx[4], g3[4], g2[4], g1[4], g0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {                                                         // :73
+      k4o[j] = cur.h6 * lo_[j];
+      k4x[j] = cur.h6 * lx_[j];
+    }
+    mv2(ATo, ATx, k4o, k4x, qy(Y4o, 2.0 * cur.tcB[0] * k4l), g3);                         // :74
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k3o[j] = __builtin_fma(cur.h, g3[j], cur.h3 * lo_[j]);    // :77
+    xmv<false>(X, ATo, ATx, k3o, qy(Y3o, 2.0 * cur.tcM[0] * k3l), kx, g2, 0.0, 0.0, nothing);  // :78
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k2o[j] = __builtin_fma(cur.hh, g2[j], cur.h3 * lo_[j]);   // :81
+    double pm = 0.0, pn = 0.0;
+    xmv<false>(X, ATo, ATx, k2o, qy(Y2o, 2.0 * cur.tcM[0] * k2l), kx, g1, 0.0, 0.0, [&]() OCS_INLINE {  // :82
+      if (OUT_DJDU) {  // midpoint column, this wave's rows   :104-106
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = k2o[j] + k3o[j];
+        pm = but_part(v);
+      }
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k1o[j] = __builtin_fma(cur.hh, g1[j], cur.h6 * lo_[j]);   // :85
+    const LQ2Pending rm = xmv<OUT_DJDU>(X, ATo, ATx, k1o, qy(yo, 2.0 * cur.tcA[0] * k1l), kx, g0, pm, 0.0,
+                                        [&]() OCS_INLINE {                                // :86-88
+      if (OUT_DJDU) {  // node column, this wave's rows   :108-112
+        double v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = k4o[j] + k1co[j];
+        pn = but_part(v);
+      }
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lo_[j] = (((lo_[j] + g1[j]) + g2[j]) + g3[j]) + g0[j];
+    // lam exchange; the next step's first stage does not depend on lam and runs under it
+    X.post<OUT_DJDU>(lo_, pn, 0.0);
+    d4 buAn = buA, buMn = buM;
+    if (!UCONST) {
+      buAn = P.bu_times(uact ? qn.uA : 0.0);
+      buMn = P.bu_times(uact ? qn.uM : 0.0);
+    }
+    const LQ2Pending rl = X.sync<OUT_DJDU>();
+    mv2(P.Ao, P.Ax, qn.yo, qn.yx, buAn, F);
+    LQ2X::take(rl, lx_);
+    store_lam();
+    if (OUT_DJDU && w == 0 && uact) {
+      dq[(size_t)(2 * i + 2) * ustride] = (pn + rl.c.x) + 2.0 * cur.tcB[0] * Rall * uB * (k4l + k1lc);
+      dq[(size_t)(2 * i + 1) * ustride] = (pm + rm.c.x) + 2.0 * cur.tcM[0] * Rall * uM * (k2l + k3l);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k1co[j] = k1o[j];
+      yo[j] = qn.yo[j];
+    }
+    k1lc = k1l;
+    eA0 = cur.tcA[0];
+    uB = uA;
+    buA = buAn;
+    buM = buMn;
+  };
+  Slot sa, sb;
+  request(N - 1, sa);
+  request(N - 2, sb);
+  {  // F1 of the first step (later steps: computed under the lam exchange of the step before)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yo[j] = sa.yo[j];
+    mv2(P.Ao, P.Ax, sa.yo, sa.yx, buA, F);
+  }
+  int i = N - 1;
+  for (; i >= 1; i -= 2) {
+    step(i, sa, sb);
+    step(i - 1, sb, sa);
+  }
+  if (i == 0) step(0, sa, sb);
+  if (OUT_DJDU) {  // first column: B(t_1, y_1, u_1)' k1_1   :100-101
+    const double p0 = but_part(k1co);
+    X.post<true>(k1co, p0, 0.0);
+    const LQ2Pending r0 = X.sync<true>();
+    if (w == 0 && uact) dq[0] = (p0 + r0.c.x) + 2.0 * eA0 * Rall * uB * k1lc;
+  }
+  if (a.lam0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (16 * w + 4 * j + g < nS) a.lam0[(size_t)(16 * w + 4 * j + g) * B + b] = lo_[j];
+    if (w == 0 && g == 0) a.lam0[(size_t)nS * B + b] = lamc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // plugin evaluation (ocs_problem_F / dFdx_times_vec / dFdu_times_vec): one thread per column
 // ---------------------------------------------------------------------------------------
 __global__ void k_lq_eval(int which, int k, int nS, int nC, const double* __restrict__ t,
@@ -488,6 +1047,13 @@ __global__ void k_lq_eval(int which, int k, int nS, int nC, const double* __rest
 // launchers
 // ---------------------------------------------------------------------------------------
 bool lq_supported(int nS, int nC) { return nS >= 1 && nS <= 32 && nC >= 1 && nC <= 4; }
+// mapping request (ocs_integrator_set_mapping): 1 = one wave per 16 trajectories, 2 = two waves; automatic: two
+// waves while that still leaves at most one wave per SIMD (1024 waves), one wave beyond
+static bool lq_two_wave(int batch, int mapping) {
+  if (mapping == MAP_LANE) return false;
+  if (mapping == MAP_ROWSPLIT) return true;
+  return batch <= 8192;  // beyond one wave per SIMD the single-wave mapping has less overhead
+}
 
 template <int RT>
 static void run_lq_forward(const LQArgs& a, bool uconst, hipStream_t s) {
@@ -505,7 +1071,36 @@ int launch_forward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const 
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
   a.x0 = x0; a.u = u; a.x = x; a.J = J; a.Jadd = o.Jadd;
-  if (p.nS <= 16) run_lq_forward<1>(a, o.uconst, s); else run_lq_forward<2>(a, o.uconst, s);
+  if (p.nS <= 16) {
+    run_lq_forward<1>(a, o.uconst, s);
+  } else if (lq_two_wave(batch, o.mapping)) {
+    const dim3 grid((batch + 31) / 32), block(256);
+#ifdef OCS_LQ_STAMPS
+    static long long* dbg = nullptr;
+    if (!dbg) (void)hipMalloc((void**)&dbg, sizeof(long long) * 8 * 65536);
+    (void)hipMemsetAsync(dbg, 0, sizeof(long long) * 8 * grid.x, s);
+    a.dbg = dbg;
+#endif
+    const bool fullp = p.nS == 32;
+    if (o.uconst)
+      fullp ? k_lq2_forward<true, true, true><<<grid, block, 0, s>>>(a) : k_lq2_forward<false, true, true><<<grid, block, 0, s>>>(a);
+    else if (a.x)
+      fullp ? k_lq2_forward<true, true, false><<<grid, block, 0, s>>>(a) : k_lq2_forward<false, true, false><<<grid, block, 0, s>>>(a);
+    else
+      fullp ? k_lq2_forward<true, false, false><<<grid, block, 0, s>>>(a) : k_lq2_forward<false, false, false><<<grid, block, 0, s>>>(a);
+#ifdef OCS_LQ_STAMPS
+    (void)hipStreamSynchronize(s);
+    std::vector<long long> h(8 * grid.x);
+    (void)hipMemcpy(h.data(), dbg, sizeof(long long) * h.size(), hipMemcpyDeviceToHost);
+    double acc[8] = {0};
+    for (unsigned q = 0; q < grid.x; ++q)
+      for (int k = 0; k < 8; ++k) acc[k] += (double)h[8 * q + k] / grid.x / ((double)g.N * 4);
+    fprintf(stderr, "[lq2 fwd] cycles per exchange, wave0: post->barrier %.0f, own half %.0f, wait partner %.0f, partner half+read %.0f"
+            " | wave1: %.0f %.0f %.0f %.0f\n", acc[0], acc[1], acc[2], acc[3], acc[4], acc[5], acc[6], acc[7]);
+#endif
+  } else {
+    run_lq_forward<2>(a, o.uconst, s);
+  }
   return hip_rc_lq(hipGetLastError());
 }
 
@@ -528,7 +1123,22 @@ int launch_backward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
   a.xck = xck; a.u = u; a.lamT = lamT; a.lam = lam; a.dJdu = dJdu; a.lam0 = o.lam0;
-  if (p.nS <= 16) run_lq_backward<1>(a, o.uconst, s); else run_lq_backward<2>(a, o.uconst, s);
+  if (p.nS <= 16) {
+    run_lq_backward<1>(a, o.uconst, s);
+  } else if (lq_two_wave(batch, o.mapping)) {
+    const dim3 grid((batch + 31) / 32), block(256);
+    const bool fullp = p.nS == 32;
+    if (o.uconst)
+      fullp ? k_lq2_backward<true, false, false, true><<<grid, block, 0, s>>>(a) : k_lq2_backward<false, false, false, true><<<grid, block, 0, s>>>(a);
+    else if (a.lam && a.dJdu)
+      fullp ? k_lq2_backward<true, true, true, false><<<grid, block, 0, s>>>(a) : k_lq2_backward<false, true, true, false><<<grid, block, 0, s>>>(a);
+    else if (a.lam)
+      fullp ? k_lq2_backward<true, true, false, false><<<grid, block, 0, s>>>(a) : k_lq2_backward<false, true, false, false><<<grid, block, 0, s>>>(a);
+    else
+      fullp ? k_lq2_backward<true, false, true, false><<<grid, block, 0, s>>>(a) : k_lq2_backward<false, false, true, false><<<grid, block, 0, s>>>(a);
+  } else {
+    run_lq_backward<2>(a, o.uconst, s);
+  }
   return hip_rc_lq(hipGetLastError());
 }
 

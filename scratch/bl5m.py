@@ -14,7 +14,7 @@ dev = torch.device("cuda:0")
 for batch in [int(b) for b in os.environ.get("BATCHES", "1024,8192,16384,32768").split(",")]:
     u = torch.tensor(rng.uniform(-1, 1, (2 * N + 1, nC, batch)), device=dev)
     x0 = torch.tensor(rng.normal(size=(nS, batch)), device=dev)
-    gi = ocs.RK4InfiniteIntegrator(tspan, tx, np.zeros(nC))
+    gi = ocs.RK4InfiniteIntegrator(tspan, tx, np.zeros(nC)); gi.set_mapping(int(os.environ.get('MAPPING', 0)))
     xd = torch.empty((N + 1, nS + 1, batch), dtype=torch.float64, device=dev); lamd = torch.empty_like(xd); dd = torch.empty_like(u)
     _, Jd = gi.compute_states_dev(prob, x0, u, xd); gi.compute_adjoints_dev(prob, u, None, lamd, dd); torch.cuda.synchronize()
     reps = 3
@@ -26,5 +26,5 @@ for batch in [int(b) for b in os.environ.get("BATCHES", "1024,8192,16384,32768")
     torch.cuda.synchronize(); tb = (time.perf_counter() - t0) / reps
     steps = batch * 2 * N   # both legs
     fl = steps * (12 * 2 * nS * nS + 3 * 2 * 2 * nS * nC + 2 * 2 * nS * nC)
-    print(f"LQ{nS} nC={nC} batch={batch} N={N}+{N}: fwd {tf*1e3:.2f} ms  bwd {tb*1e3:.2f} ms  pair {1e3*(tf+tb):.2f} ms  "
+    print(f"map={os.environ.get('MAPPING', 0)} LQ{nS} nC={nC} batch={batch} N={N}+{N}: fwd {tf*1e3:.2f} ms  bwd {tb*1e3:.2f} ms  pair {1e3*(tf+tb):.2f} ms  "
           f"{steps/(tf+tb):.3e} steps/s (both legs)  {fl/(tf+tb)/1e12:.2f} TFLOP/s  finite={bool(torch.isfinite(lamd).all())}", flush=True)

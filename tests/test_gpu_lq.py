@@ -43,9 +43,10 @@ def test_plugin_methods(ocs, oracle, nS, nC):
     assert relerr(pg.dFdu_times_vec(t, y, u, v), po.dFdu_times_vec(t, y, u, v)) < 1e-13
 
 
-@pytest.mark.parametrize("nS,nC,N,batch", [(1, 1, 7, 3), (5, 2, 33, 37), (16, 4, 64, 16), (20, 3, 50, 50),
+@pytest.mark.parametrize("mapping", [0, 1, 2])
+@pytest.mark.parametrize("nS,nC,N,batch", [(1, 1, 7, 3), (5, 2, 33, 37), (16, 4, 64, 16), (17, 2, 20, 19), (20, 3, 50, 50),
                                            (32, 4, 96, 68), (32, 1, 3, 1)])
-def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch):
+def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch, mapping):
     pg, po = make(ocs, oracle, nS, nC)
     rng = np.random.default_rng(N)
     tspan = np.concatenate([[0.0], np.sort(rng.uniform(0.0, 1.5, N - 1)), [1.5]]) if N > 3 else oracle.linspace(0, 0.1, N + 1)
@@ -53,6 +54,7 @@ def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch):
     x0 = rng.normal(size=(nS, batch))
     lamT = rng.normal(size=(nS + 1, batch))
     g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    g.set_mapping(mapping)   # 0: automatic (two waves per 16 trajectories when nS > 16), 1: one wave
     x, J = g.compute_states(pg, x0, u)
     lam, dJdu = g.compute_adjoints(pg, u)
     for b in sorted({0, batch // 2, batch - 1}):
@@ -70,7 +72,8 @@ def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch):
         assert relerr(lam2[:, :, b], lamo) < RTOL and relerr(d2[:, :, b], do) < RTOL
 
 
-def test_infinite_horizon_and_shooting_objective(ocs, oracle):
+@pytest.mark.parametrize("mapping", [0, 1, 2])
+def test_infinite_horizon_and_shooting_objective(ocs, oracle, mapping):
     """BL-5 shape at reduced size: nS = 32, nC = 4, RK4InfiniteIntegrator with uStar = 0, then the shooting objective
     (single_shooting.m:137-150) through a PWLinear basis with nC = 4 and a free initial state."""
     nS, nC, N, batch = 32, 4, 80, 40
@@ -81,6 +84,7 @@ def test_infinite_horizon_and_shooting_objective(ocs, oracle):
     x0 = rng.normal(size=(nS, batch))
     ustar = np.array([0.1, -0.2, 0.0, 0.3])
     gi, go = ocs.RK4InfiniteIntegrator(tspan, tx, ustar), oracle.RK4InfiniteIntegrator(tspan, tx, ustar)
+    gi.set_mapping(mapping)
     x, J = gi.compute_states(pg, x0, u)
     lam, dJdu = gi.compute_adjoints(pg, u)
     for b in (0, 17, 39):
