@@ -173,6 +173,10 @@ int ocs_nlp_objective(ocs_integrator g, ocs_problem p, ocs_control c, int batch,
 int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int batch, double *x0,
                           const double *v, int nFree, const int *FreeInitStates, double *J, double *dJdv,
                           void *stream);
+/* For a dense basis with at most 32 functions (ChebyshevControl) on an RK4Integrator, nlpObjective can apply
+ * the basis inside the RK4 kernels (u and dJdu are never materialised).  mode: 0 automatic (large batches),
+ * 1 never, 2 whenever supported.  Results are the same up to the summation order of dJdu*B'. */
+int ocs_control_set_fusion(ocs_control c, int mode);
 
 /* ---- forward-backward sweep (functions/fb_sweep.m, compute_x_lam.m, compute_x_lam_J.m) ----
  * Gen-1 drivers run on a Gen-2 OCProblem through the adapter stateRHS = F(1:nS), objective = F(end),

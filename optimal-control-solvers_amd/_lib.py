@@ -55,6 +55,7 @@ _SIG = {
     "ocs_rk4_create": (C.c_int, [C.POINTER(vp), dp, C.c_int]),
     "ocs_integrator_destroy": (C.c_int, [vp]),
     "ocs_integrator_set_mapping": (C.c_int, [vp, C.c_int]),
+    "ocs_control_set_fusion": (C.c_int, [vp, C.c_int]),
     "ocs_integrator_nsteps": (C.c_int, [vp, ip]),
     "ocs_integrator_t": (C.c_int, [vp, dp]),
     "ocs_integrator_h": (C.c_int, [vp, dp]),

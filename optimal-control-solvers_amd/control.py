@@ -97,6 +97,16 @@ class Control:
         return uFunc
 
 
+def _set_fusion(self, mode):
+    """Where the basis is dense with <= 32 functions, nlp_objective can apply it inside the RK4 kernels:
+    "auto" (large batches), "off", "on" (whenever supported)."""
+    check(lib.ocs_control_set_fusion(self._h, {"auto": 0, "off": 1, "on": 2}[mode]))
+    return self
+
+
+Control.set_fusion = _set_fusion
+
+
 class _BoundedControl(Control):
     def compute_nlp_bounds(self, controlBounds):
         """[Lb, Ub] = compute_nlp_bounds(obj, controlBounds)."""

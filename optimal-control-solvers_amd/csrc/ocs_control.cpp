@@ -13,7 +13,8 @@ struct ocs_control_s {
   std::vector<double> t, pts, B;  // B: nBasis x nT column-major (property B)
   double t0 = 0, t1 = 0;
   // device copies: CSC (for u = v*B) and CSR (for dJdv = dJdu*B')
-  DevBuf d_colptr, d_row, d_cval, d_rowptr, d_col, d_rval, d_BT;
+  DevBuf d_colptr, d_row, d_cval, d_rowptr, d_col, d_rval, d_BT, d_BT16;
+  int fuse_mode = 0;  // ocs_control_set_fusion: 0 automatic, 1 never, 2 whenever the fused kernels support the case
   bool dense = false;  // more than half of B is non-zero and nBasis <= 32: register-resident dense kernels
   bool uploaded = false;
   hipStream_t stream = nullptr;
@@ -144,6 +145,13 @@ static int upload_control(ocs_control_s* c) {
       for (int i = 0; i < nB; ++i) BT[(size_t)j * nB + i] = c->B[i + (size_t)nB * j];
     OCS_TRY(c->d_BT.ensure(sizeof(double) * BT.size()));
     HIP_TRY(hipMemcpy(c->d_BT.p, BT.data(), sizeof(double) * BT.size(), hipMemcpyHostToDevice));
+    // the same table padded to whole groups of 16 functions: layout of the fused-control kernels
+    const int ld = nB <= 16 ? 16 : 32;
+    std::vector<double> BT16((size_t)nT * ld, 0.0);
+    for (int j = 0; j < nT; ++j)
+      for (int i = 0; i < nB; ++i) BT16[(size_t)j * ld + i] = c->B[i + (size_t)nB * j];
+    OCS_TRY(c->d_BT16.ensure(sizeof(double) * BT16.size()));
+    HIP_TRY(hipMemcpy(c->d_BT16.p, BT16.data(), sizeof(double) * BT16.size(), hipMemcpyHostToDevice));
   }
   if (!c->stream) HIP_TRY(hipStreamCreate(&c->stream));
   c->uploaded = true;
@@ -222,7 +230,7 @@ int ocs_control_create(ocs_control* out, int kind, const double* t, int nt, int 
 int ocs_control_destroy(ocs_control c) {
   if (!c) return OCS_OK;
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  DevBuf* bufs[] = {&c->d_colptr, &c->d_row, &c->d_cval, &c->d_rowptr, &c->d_col, &c->d_rval, &c->d_BT, &c->d_v,
+  DevBuf* bufs[] = {&c->d_colptr, &c->d_row, &c->d_cval, &c->d_rowptr, &c->d_col, &c->d_rval, &c->d_BT, &c->d_BT16, &c->d_v,
                     &c->d_u, &c->d_dJdu, &c->d_dJdv, &c->d_stage, &c->d_x0, &c->d_J, &c->d_idx};
   for (DevBuf* b : bufs) b->release();
   delete c;
@@ -408,9 +416,17 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   OCS_TRY(upload_control(c));
   const int nV = c->nC * c->nBasis, nU = c->nC * c->nT, nAug = p->nS + 1;
   const size_t B = (size_t)batch;
-  OCS_TRY(c->d_u.ensure(sizeof(double) * (size_t)nU * B));
-  OCS_TRY(c->d_dJdu.ensure(sizeof(double) * (size_t)nU * B));
-  OCS_TRY(ocs_control_compute_u_dev(c, batch, v, c->d_u.d(), stream));                       // :139 / :145
+  // Dense basis with few functions on a plain RK4Integrator: u and dJdu never touch memory, the basis is
+  // applied inside the RK4 kernels (ocs_fused_control_kernels.hip).  Measured on TestOCProblem + Chebyshev-16,
+  // N = 1000 (ms per evaluation, unfused / fused): batch 64 0.80 / 0.43, 4096 0.90 / 0.44, 65536 2.54 / 0.61,
+  // 262144 6.28 / 2.02.  With 3-4 states and a small batch the wave-specialised unfused passes are kept.
+  const bool fusable = c->dense && g->kind == 0 && fused_control_supported(p->functor, p->nS, p->nC, c->nBasis);
+  const bool fused = fusable && c->fuse_mode != 1 && (c->fuse_mode == 2 || p->nS <= 2 || batch >= 8192);
+  if (!fused) {
+    OCS_TRY(c->d_u.ensure(sizeof(double) * (size_t)nU * B));
+    OCS_TRY(c->d_dJdu.ensure(sizeof(double) * (size_t)nU * B));
+    OCS_TRY(ocs_control_compute_u_dev(c, batch, v, c->d_u.d(), stream));                     // :139 / :145
+  }
   if (nFree > 0) {
     std::vector<int> idx(nFree);
     for (int f = 0; f < nFree; ++f) {
@@ -423,10 +439,21 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
     HIP_TRY(hipStreamSynchronize(s));  // idx is a stack vector
     LAUNCH_TRY(launch_scatter_rows(nFree, batch, (const int*)c->d_idx.p, v + (size_t)nV * B, x0, s));  // :146
   }
-  OCS_TRY(ocs_compute_states_dev(g, p, batch, x0, c->d_u.d(), nullptr, J, stream));         // :140 / :147
   double* lam0 = nullptr;
   if (nFree > 0)
     lam0 = reinterpret_cast<double*>(static_cast<char*>(c->d_idx.p) + ((sizeof(int) * nFree + 7) / 8) * 8);
+  if (fused) {
+    OCS_TRY(bind_problem(g, p, batch, s));
+    OCS_TRY(g->d_ck.ensure(sizeof(double) * (size_t)nAug * (g->N + 1) * B));
+    g->ck = nullptr;  // these checkpoints belong to no u in memory: a later compute_adjoints must not use them
+    LAUNCH_TRY(launch_forward_fc(describe(p), describe(g), batch, c->nBasis, c->d_BT16.d(), v, x0, g->d_ck.d(), J, s));
+    LAUNCH_TRY(launch_backward_fc(describe(p), describe(g), batch, c->nBasis, c->d_BT16.d(), v, g->d_ck.d(), dJdv,
+                                  lam0, s));
+    if (nFree > 0)
+      LAUNCH_TRY(launch_gather_rows(nFree, batch, (const int*)c->d_idx.p, lam0, dJdv + (size_t)nV * B, s));
+    return OCS_OK;
+  }
+  OCS_TRY(ocs_compute_states_dev(g, p, batch, x0, c->d_u.d(), nullptr, J, stream));         // :140 / :147
   g->want_lam0 = lam0;
   const int rc = ocs_compute_adjoints_dev(g, p, batch, c->d_u.d(), nullptr, nullptr, c->d_dJdu.d(), stream);  // :141 / :148
   g->want_lam0 = nullptr;
@@ -434,6 +461,13 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   OCS_TRY(ocs_control_compute_dJdv_dev(c, batch, c->d_dJdu.d(), dJdv, stream));              // :142 / :149
   if (nFree > 0)                                                                              // lam(FreeInitStates,1)
     LAUNCH_TRY(launch_gather_rows(nFree, batch, (const int*)c->d_idx.p, lam0, dJdv + (size_t)nV * B, s));
+  return OCS_OK;
+}
+
+int ocs_control_set_fusion(ocs_control c, int mode) {
+  if (!c) return fail(OCS_ERR_INVALID, "null control");
+  if (mode < 0 || mode > 2) return fail(OCS_ERR_INVALID, "fusion mode must be 0 (automatic), 1 (off) or 2 (on)");
+  c->fuse_mode = mode;
   return OCS_OK;
 }
 

@@ -101,6 +101,14 @@ int launch_fill_rows(int ncols, int nC, int batch, const double* val, double* ou
 int launch_gather_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
 int launch_scatter_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
 
+// shooting objective + gradient with the (dense, <= 32 functions) control basis fused into the RK4 kernels
+// (ocs_fused_control_kernels.hip).  BT16: transposed basis [2N+1][16 or 32], zero-padded (16 when nBasis <= 16)
+bool fused_control_supported(Functor f, int nS, int nC, int nBasis);
+int launch_forward_fc(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, const double* BT16,
+                      const double* v, const double* x0, double* ck, double* J, hipStream_t s);
+int launch_backward_fc(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, const double* BT16,
+                       const double* v, const double* ck, double* dJdv, double* lam0, hipStream_t s);
+
 // forward-backward sweep (ocs_fbs_kernels.hip)
 struct FbsTables {   // pchip node tables of an integrator grid, device pointers
   int n;             // number of nodes N+1

@@ -1,20 +1,25 @@
+"""BL-4 timing: Chebyshev-16 objective+gradient, batch sweep, fused vs unfused."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import __graft_entry__ as g
 ocs = g.load_package()
-dev = torch.device('cuda:0')
-N, nB = 1000, 16
-for batch in (8192, 65536):
+dev = torch.device("cuda:0")
+N = 1000
+integ = ocs.RK4Integrator(np.linspace(0.0, 10.0, N + 1))
+prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
+ctrl = ocs.ChebyshevControl(integ.t, 16, 1)
+for batch in [int(b) for b in os.environ.get("BATCHES", "8192,16384,65536,262144").split(",")]:
     rng = np.random.default_rng(20260403)
-    V = 0.05 * rng.normal(size=(nB, batch)) / np.arange(1, nB + 1)[:, None]; V[0] += 0.5
-    integ = ocs.RK4Integrator(np.linspace(0, 10, N + 1))
-    prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
-    ctrl = ocs.ChebyshevControl(integ.t, nB, 1)
+    V = 0.05 * rng.normal(size=(16, batch)) / np.arange(1, 17)[:, None]; V[0] += 0.5
     vd = torch.tensor(V, device=dev); x0 = torch.ones((1, batch), dtype=torch.float64, device=dev)
     J = torch.empty(batch, dtype=torch.float64, device=dev); G = torch.empty_like(vd)
-    for _ in range(3): ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
-    torch.cuda.synchronize(); t0 = time.perf_counter(); reps = 10
-    for _ in range(reps): ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
-    torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / reps
-    print(f"BL-4 batch={batch}: {dt*1e3:.3f} ms per objective+gradient evaluation of the batch, {batch*N/dt:.3e} steps/s, "
-          f"alg(32 B/step) {32*batch*N/dt/1e9:.0f} GB/s")
+    res = {}
+    for mode in ("off", "on"):
+        ctrl.set_fusion(mode)
+        for _ in range(2): ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for _ in range(5): ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
+        torch.cuda.synchronize(); res[mode] = ((time.perf_counter() - t0) / 5, J.clone(), G.clone())
+    dJ = float((res["on"][1] - res["off"][1]).abs().max()); dG = float((res["on"][2] - res["off"][2]).abs().max())
+    print(f"batch={batch}: unfused {res['off'][0]*1e3:.3f} ms  fused {res['on'][0]*1e3:.3f} ms  "
+          f"({batch*N/res['on'][0]:.3e} steps/s)  max|dJ|={dJ:.2e} max|dG|={dG:.2e}", flush=True)

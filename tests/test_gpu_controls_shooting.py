@@ -228,3 +228,43 @@ def test_dense_basis_kernels_large_batch(ocs, oracle):
         vb = v[:, :, b].reshape(-1)                       # control index fastest within a basis function
         assert relerr(u[:, :, b].T, co.compute_u(vb)) < 1e-13
         assert relerr(dv[:, :, b].reshape(-1), co.compute_dJdv(d[:, :, b].T)) < 1e-12
+
+
+@pytest.mark.parametrize("nS,nB,N,batch", [(1, 16, 1000, 70), (1, 5, 7, 3), (2, 20, 50, 130), (4, 32, 64, 64),
+                                           (3, 1, 9, 65)])
+def test_fused_control_objective_gradient(ocs, oracle, nS, nB, N, batch):
+    """single_shooting.m:137-150 with ChebyshevControl.m:35-43 applied inside the RK4 kernels (u and dJdu never in
+    memory) against the oracle's unfused composition and against this library's own unfused path; free initial
+    states (:144-149) and a per-trajectory parameter included."""
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    T = 10.0 if N >= 50 else 1.0
+    tspan = oracle.linspace(0, T, N + 1)
+    g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    cg, co = ocs.ChebyshevControl(g.t, nB, 1), oracle.ChebyshevControl(go.t, nB, 1)
+    rng = np.random.default_rng(nB * 100 + N)
+    free = [nS, 1] if nS > 1 else [1]
+    V = 0.05 * rng.normal(size=(nB, batch)) / np.arange(1, nB + 1)[:, None]
+    V[0] += 0.4
+    V = np.vstack([V, rng.uniform(0.8, 1.6, (len(free), batch))])
+    cs = rng.uniform(1.0, 2.0, batch)
+    x0 = rng.uniform(0.8, 1.5, (nS, batch))
+    pg = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    pg.set_batch_params([0], cs[None, :])   # LogisticK parameter block [c r m_1..m_nS]: c per trajectory
+    out = {}
+    for mode in ("on", "off"):
+        cg.set_fusion(mode)
+        out[mode] = ocs.nlp_objective(g, pg, cg, x0.copy(), V, FreeInitStates=free)
+    Jf, df, x0f = out["on"]
+    Ju, du, x0u = out["off"]
+    assert relerr(Jf, Ju) < 1e-13 and relerr(df, du) < RTOL and np.array_equal(x0f, x0u)
+    for b in sorted({0, batch // 2, batch - 1}):
+        po = oracle.LogisticProblem(m, cs[b], P["r"], BOUNDS)
+        Jo, do, x0o = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b], FreeInitStates=free)
+        assert abs(Jf[b] - Jo) < RTOL * max(1.0, abs(Jo)) and relerr(df[:, b], do) < RTOL
+        assert np.array_equal(x0f[:, b], x0o)
+    # the fused pass leaves no forward pass behind that compute_adjoints could pair with a control array
+    cg.set_fusion("on")
+    ocs.nlp_objective(g, pg, cg, x0.copy(), V, FreeInitStates=free)
+    with pytest.raises(Exception):
+        g.compute_adjoints(pg, np.zeros((1, 2 * N + 1, batch)))
+    cg.set_fusion("auto")
