@@ -88,7 +88,7 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=3):
     One iter = forward + costate + control update + convergence reduction for one instance; converged
     instances stop counting (the whole batch still runs until the last one is done)."""
     rng = np.random.default_rng(20260402)
-    tspan = np.linspace(0.0, T_END, NSTEPS + 1)
+    tspan = ocs.linspace(0.0, T_END, NSTEPS + 1)  # MATLAB's linspace, as fb_sweep.m:69-70 builds its point sets
     x0 = torch.tensor(rng.uniform(0.5, 2.5, (1, batch)), device=dev)
     cs = rng.uniform(1.0, 2.0, batch)
     prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
@@ -180,7 +180,7 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2):
     tfl_b = steps * fl_bwd / tb / 1e12
     return {"value": steps / (tf + tb), "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
             "batch": batch, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3, "ms_adjoint": tb * 1e3,
-            "roofline": {"bound": "mfma", "kernel": "k_lq_backward<2> (adjoint + dJdu, both legs)",
+            "roofline": {"bound": "mfma", "kernel": "k_lq2_backward (adjoint + dJdu, both legs; two waves per 16 trajectories)",
                          "achieved": tfl_b, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": tfl_b / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
                          "algorithmic_flops_per_trajectory_step": fl_bwd},

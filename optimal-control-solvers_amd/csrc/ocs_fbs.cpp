@@ -9,7 +9,7 @@ using namespace ocs;
 
 struct ocs_fbs_state {
   // pchip node tables
-  DevBuf TN, HN, W1, W2, TM;
+  DevBuf TN, HN, W1, W2, TM, IH;
   bool tables = false;
   // query-point tables (error points / interp points), rebuilt when the options change
   int nerr = 0, nint = 0;
@@ -22,7 +22,7 @@ struct ocs_fbs_state {
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
   if (!s) return;
-  DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
+  DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->IH, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
                     &s->TI, &s->TUI, &s->xaug, &s->xmid, &s->lam, &s->lmid, &s->ugrid, &s->uerr, &s->uint_, &s->J,
                     &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage, &s->metric, &s->anyvalid};
   for (DevBuf* b : bufs) b->release();
@@ -66,13 +66,16 @@ static int ensure_tables(ocs_integrator_s* g) {
   OCS_TRY(upload(f->W1, w1.data(), sizeof(double) * n));
   OCS_TRY(upload(f->W2, w2.data(), sizeof(double) * n));
   OCS_TRY(upload(f->TM, tm.data(), sizeof(double) * N));
+  std::vector<double> ih(N);
+  for (int i = 0; i < N; ++i) ih[i] = 1.0 / h[i];
+  OCS_TRY(upload(f->IH, ih.data(), sizeof(double) * N));
   f->tables = true;
   return OCS_OK;
 }
 
 static FbsTables tabs(const ocs_integrator_s* g) {
   const ocs_fbs_state* f = g->fbs;
-  return FbsTables{g->N + 1, f->TN.d(), f->HN.d(), f->W1.d(), f->W2.d(), f->TM.d()};
+  return FbsTables{g->N + 1, f->TN.d(), f->HN.d(), f->W1.d(), f->W2.d(), f->TM.d(), f->IH.d()};
 }
 
 // interval index and local coordinate of query points linspace(T0, TF, nq)
@@ -188,15 +191,13 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   }
   const size_t ugridN = (size_t)nT * nC * B, uerrN = (size_t)nE * nC * B;
   OCS_TRY(f->xmid.ensure(sizeof(double) * (size_t)N * nS * B));
-  OCS_TRY(f->lmid.ensure(sizeof(double) * (size_t)N * nS * B));
   OCS_TRY(f->ugrid.ensure(sizeof(double) * ugridN));
-  OCS_TRY(f->uerr.ensure(sizeof(double) * 2 * uerrN));
+  OCS_TRY(f->uerr.ensure(sizeof(double) * uerrN));
   OCS_TRY(f->usel.ensure(sizeof(int) * B));
   OCS_TRY(f->nactive.ensure(sizeof(int)));
-  OCS_TRY(f->metric.ensure(sizeof(unsigned long long) * B));
+  const int nparts = control_pts_parts(nE);
+  OCS_TRY(f->metric.ensure(sizeof(double) * (size_t)nparts * B));
   OCS_TRY(f->anyvalid.ensure(sizeof(int) * B));
-  HIP_TRY(hipMemsetAsync(f->metric.p, 0, sizeof(unsigned long long) * B, s));
-  HIP_TRY(hipMemsetAsync(f->anyvalid.p, 0, sizeof(int) * B, s));
   double* mc = maxChange;
   if (!mc) {
     OCS_TRY(f->maxchange.ensure(sizeof(double) * (size_t)opt->nSWEEPS * B));
@@ -227,14 +228,14 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     // (:81, :99-115) folded in
     HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));
     LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
-                                  f->uerr.d(), usel, (long long)uerrN, (unsigned long long*)f->metric.p,
+                                  f->uerr.d(), usel, (long long)uerrN, f->metric.d(),
                                   (int*)f->anyvalid.p, opt->uRelTol, opt->uAbsTol, s));
-    LAUNCH_TRY(launch_fbs_advance(batch, sweep, (unsigned long long*)f->metric.p, (int*)f->anyvalid.p,
+    LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p,
                                   (int*)f->usel.p, status, mc, (int*)f->nactive.p, s));
     // u = uNew (:85) on the integrator grid, only for the instances that continue: a converged instance
     // keeps its OLD control, which is what final_sweep(u) integrates (:82)
-    LAUNCH_TRY(launch_pchip_mid(tb, nS, nS, batch, lam, f->lmid.d(), s));
-    LAUNCH_TRY(launch_control_grid(pd, gd, batch, xaug, nAug, f->xmid.d(), lam, f->lmid.d(), f->ugrid.d(), status, s));
+    // (lam's pchip midpoints are formed inside the kernel)
+    LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, f->xmid.d(), lam, f->ugrid.d(), status, s));
     HIP_TRY(hipMemcpyAsync(&nactive, f->nactive.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }

@@ -28,13 +28,14 @@ __device__ static inline double pchip_end(double h0, double h1, double del0, dou
   return d;
 }
 
-// Node tables (uniform): TN[0..n-1] node times, HN[0..n-2] spacings, W1/W2[1..n-2] slope weights.
+// Node tables (uniform): TN[0..n-1] node times, HN[0..n-2] spacings, W1/W2[1..n-2] slope weights, IH = 1./HN.
 struct PchipTab {
   int n;
   const double* TN;
   const double* HN;
   const double* W1;
   const double* W2;
+  const double* IH;  // 1 ./ HN
 };
 
 // slope at node k of the samples v(k) = V[(k*ld + row)*B + b]
@@ -53,28 +54,108 @@ __device__ static inline double pchip_slope_at(const PchipTab& T, const double* 
   const double d0 = (val(k) - val(k - 1)) / T.HN[k - 1], d1 = (val(k + 1) - val(k)) / T.HN[k];
   return pchip_interior(d0, d1, T.W1[k], T.W2[k]);
 }
-// interpolant in interval k at local coordinate s = q - TN[k]
-__device__ static inline double pchip_eval(const PchipTab& T, const double* V, size_t ldB, int k, double s) {
-  const double v0 = V[(size_t)k * ldB], v1 = V[(size_t)(k + 1) * ldB];
-  const double h = T.HN[k];
-  const double dk = pchip_slope_at(T, V, ldB, k), dk1 = pchip_slope_at(T, V, ldB, k + 1);
+// cubic Hermite piece on an interval of length h with end values v0, v1 and end slopes dk, dk1 (pwch + ppval)
+__device__ static inline double pchip_piece(double v0, double v1, double dk, double dk1, double h, double s) {
   const double del = (v1 - v0) / h;
   const double dzzdx = (del - dk) / h, dzdxdx = (dk1 - del) / h;
   const double c3 = (dzdxdx - dzzdx) / h, c2 = 2.0 * dzzdx - dzdxdx;
   return v0 + s * (dk + s * (c2 + s * c3));
 }
+// interpolant in interval k at local coordinate s = q - TN[k]
+__device__ static inline double pchip_eval(const PchipTab& T, const double* V, size_t ldB, int k, double s) {
+  const double v0 = V[(size_t)k * ldB], v1 = V[(size_t)(k + 1) * ldB];
+  const double dk = pchip_slope_at(T, V, ldB, k), dk1 = pchip_slope_at(T, V, ldB, k + 1);
+  return pchip_piece(v0, v1, dk, dk1, T.HN[k], s);
+}
+
+// interior slope from the two neighbouring secants: pchip_interior with one division less -- of del0/dmax and
+// del1/dmax one is exactly +-1 and the other is +-(dmin/dmax), so the denominator is bit-identical
+__device__ static inline double pchip_interior2(double del0, double del1, double w1, double w2) {
+  if (dsgn(del0) * dsgn(del1) <= 0) return 0.0;
+  const double a0 = fabs(del0), a1 = fabs(del1);
+  const double sg = del0 > 0.0 ? 1.0 : -1.0;
+  const bool first = a0 >= a1;  // dmax = a0
+  const double dmax = first ? a0 : a1, dmin = first ? a1 : a0;
+  const double q = sg * (dmin / dmax);
+  const double r0 = first ? sg : q, r1 = first ? q : sg;
+  return dmin / (w1 * r0 + w2 * r1);
+}
+
+// One value in each of R consecutive intervals i0 .. i0+R-1 of one sample row, at local coordinates sv[c]:
+// R+4 loads, each secant and each node slope once (not once per adjacent interval), R cubic pieces.  Divisions by
+// the spacing use the reciprocal table IH (round-off level difference to pchip_eval's true divisions).  mid[c]
+// is valid for i0 + c < n - 1.
+constexpr int kPchipRun = 8;
+template <int R>
+__device__ static inline void pchip_run(const PchipTab& T, const double* V, size_t ldB, int i0, const double (&sv)[R],
+                                        double (&mid)[R]) {
+  const int n = T.n;
+  auto clampi = [&](int k, int hi) OCS_INLINE { return k < 0 ? 0 : (k > hi ? hi : k); };
+  double w[R + 4];  // w[j] = v(i0 - 2 + j); clamped entries are never used by a valid result
+#pragma unroll
+  for (int j = 0; j < R + 4; ++j) w[j] = V[(size_t)clampi(i0 - 2 + j, n - 1) * ldB];
+  double sec[R + 3];  // sec[j] = secant of interval i0 - 2 + j
+#pragma unroll
+  for (int j = 0; j < R + 3; ++j) sec[j] = (w[j + 1] - w[j]) * T.IH[clampi(i0 - 2 + j, n - 2)];
+  double d[R + 1];
+#pragma unroll
+  for (int c = 0; c <= R; ++c) {
+    const int k = i0 + c;  // node; intervals k-1 and k are sec[c+1], sec[c+2]
+    double dk;
+    if (n == 2)
+      dk = sec[2];  // N = 1: the only interval is sec[2] (i0 = 0)
+    else if (k == 0)
+      dk = pchip_end(T.HN[0], T.HN[1], sec[c + 2], sec[c + 3]);
+    else if (k == n - 1)
+      dk = pchip_end(T.HN[n - 2], T.HN[n - 3], sec[c + 1], sec[c]);
+    else if (k < n - 1)
+      dk = pchip_interior2(sec[c + 1], sec[c + 2], T.W1[k], T.W2[k]);
+    else
+      dk = 0.0;
+    d[c] = dk;
+  }
+#pragma unroll
+  for (int c = 0; c < R; ++c) {
+    const int i = i0 + c;
+    double m = 0.0;
+    if (i < n - 1) {
+      const double ih = T.IH[i], s = sv[c], del = sec[c + 2];
+      const double dzzdx = (del - d[c]) * ih, dzdxdx = (d[c + 1] - del) * ih;
+      const double c3 = (dzdxdx - dzzdx) * ih, c2 = 2.0 * dzzdx - dzdxdx;
+      m = w[c + 2] + s * (d[c] + s * (c2 + s * c3));
+    }
+    mid[c] = m;
+  }
+}
+
+template <int R>
+__device__ static inline void pchip_mid_run(const PchipTab& T, const double* V, size_t ldB, int i0,
+                                            const double* __restrict__ TM, double (&mid)[R]) {
+  double sv[R];
+#pragma unroll
+  for (int c = 0; c < R; ++c) {
+    const int i = i0 + c < T.n - 1 ? i0 + c : T.n - 2;
+    sv[c] = TM[i] - T.TN[i];
+  }
+  pchip_run<R>(T, V, ldB, i0, sv, mid);
+}
 
 // midpoint samples: out[i][r][b] = pchip(V(r,:))(t_mid_i)   for rows r < nrows of V [n][ld][B]
+// blockIdx.y = run of kPchipRun intervals
 __global__ __launch_bounds__(256) void k_pchip_mid(PchipTab T, int nrows, int ld, int batch,
                                                    const double* __restrict__ TM, const double* __restrict__ V,
                                                    double* __restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (b >= batch || i >= T.n - 1) return;
+  const int i0 = blockIdx.y * kPchipRun;
+  if (b >= batch || i0 >= T.n - 1) return;
   const size_t B = (size_t)batch;
-  const double s = TM[i] - T.TN[i];
-  for (int r = 0; r < nrows; ++r)
-    out[((size_t)i * nrows + r) * B + b] = pchip_eval(T, V + (size_t)r * B + b, (size_t)ld * B, i, s);
+  for (int r = 0; r < nrows; ++r) {
+    double mid[kPchipRun];
+    pchip_mid_run<kPchipRun>(T, V + (size_t)r * B + b, (size_t)ld * B, i0, TM, mid);
+#pragma unroll
+    for (int c = 0; c < kPchipRun; ++c)
+      if (i0 + c < T.n - 1) out[((size_t)(i0 + c) * nrows + r) * B + b] = mid[c];
+  }
 }
 
 // ---------------------------------------------------------------------------------------
@@ -247,8 +328,9 @@ struct ControlGridArgs {
   const double* x;     // [N+1][ldx][B]
   int ldx;
   const double* xmid;  // [N][nS][B]
-  const double* lam;   // [N+1][nS][B]
-  const double* lmid;  // [N][nS][B]
+  const double* lam;   // [N+1][nS][B]; its pchip midpoints are formed here (one run of intervals per thread)
+  PchipTab T;
+  const double* TM;
   double* u;           // the control grid, updated in place
   const int* status;   // only instances that are still active (status 0) take the new control (fb_sweep.m:85);
                        // a converged instance keeps its old one for the final sweep (:82)
@@ -256,43 +338,64 @@ struct ControlGridArgs {
 
 template <class P>
 __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
-  constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU;
+  constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU, R = kPchipRun;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int j = blockIdx.y;  // grid point
+  const int i0 = blockIdx.y * R;  // first interval of this thread's run
   if (b >= a.batch || a.status[b] != 0) return;
   const size_t B = (size_t)a.batch;
+  const int N = a.N;
   const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
-  double x[NS], lam[NS], tu[NTU], lb[NC], ub[NC], u[NC];
-  const int i = j >> 1;
-  if (j & 1) {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      x[k] = a.xmid[((size_t)i * NS + k) * B + b];
-      lam[k] = a.lmid[((size_t)i * NS + k) * B + b];
-    }
-  } else {
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      x[k] = a.x[((size_t)i * a.ldx + k) * B + b];
-      lam[k] = a.lam[((size_t)i * NS + k) * B + b];
-    }
-  }
-#pragma unroll
-  for (int k = 0; k < NTU; ++k) tu[k] = a.TU[(size_t)j * NTU + k];
+  double lb[NC], ub[NC];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     lb[c] = a.lb[c];
     ub[c] = a.ub[c];
   }
-  P::control_char(tu, x, lam, p, lb, ub, u);
+  double lmid[NS][R];
 #pragma unroll
-  for (int c = 0; c < NC; ++c) a.u[((size_t)j * NC + c) * B + b] = u[c];
+  for (int k = 0; k < NS; ++k) pchip_mid_run<R>(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i0, a.TM, lmid[k]);
+  auto emit = [&](int j, const double* x, const double* lam) OCS_INLINE {  // grid point j
+    double tu[NTU], u[NC];
+#pragma unroll
+    for (int k = 0; k < NTU; ++k) tu[k] = a.TU[(size_t)j * NTU + k];
+    P::control_char(tu, x, lam, p, lb, ub, u);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) a.u[((size_t)j * NC + c) * B + b] = u[c];
+  };
+#pragma unroll
+  for (int c = 0; c < R; ++c) {
+    const int i = i0 + c;
+    if (i < N) {
+      double x[NS], lam[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        x[k] = a.x[((size_t)i * a.ldx + k) * B + b];
+        lam[k] = a.lam[((size_t)i * NS + k) * B + b];
+      }
+      emit(2 * i, x, lam);
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        x[k] = a.xmid[((size_t)i * NS + k) * B + b];
+        lam[k] = lmid[k][c];
+      }
+      emit(2 * i + 1, x, lam);
+    }
+  }
+  if (i0 + R >= N) {  // the run that ends the grid also owns the last node
+    double x[NS], lam[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      x[k] = a.x[((size_t)N * a.ldx + k) * B + b];
+      lam[k] = a.lam[((size_t)N * NS + k) * B + b];
+    }
+    emit(2 * N, x, lam);
+  }
 }
 
 // ---------------------------------------------------------------------------------------
 // control at arbitrary points: out[q][c][b] = ControlChar(tq, x(tq), lam(tq)) with pchip x, lam
 // (errorPts fb_sweep.m:107, interpPts :123).  KQ/SQ: interval index and local coordinate of tq.
-// If usel is given the result goes to buffer 1 - usel[b] (out + that * odelta).
+// With `metric` set this is the error-point mode of the sweep: out is read (old control) and replaced in place.
 // ---------------------------------------------------------------------------------------
 struct ControlPtsArgs {
   int nq, batch;
@@ -313,8 +416,8 @@ struct ControlPtsArgs {
   long long odelta;
   // error-point mode (usel != nullptr): the weighted change |uNew - u| / (relTol |u| + absTol) against the
   // instance's current buffer is folded into metric[b] (bit pattern of a non-negative double, atomicMax)
-  unsigned long long* metric;
-  int* anyvalid;
+  double* metric;  // [blocks in y][B]: this block's maximum for instance b, or -1 if none of its values was valid
+  int* anyvalid;   // unused (kept for the argument layout)
   double relTol, absTol;
 };
 
@@ -328,16 +431,47 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   double wmax = 0.0;
   bool any = false;
   const int q0 = (int)blockIdx.y * kPtsPerThread;
-  for (int q = q0; q < q0 + kPtsPerThread && q < a.nq; ++q) {
   const size_t B = (size_t)a.batch;
-  const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
-  const int k0 = a.KQ[q];
-  const double s = a.SQ[q];
-  double x[NS], lam[NS], tu[NTU], lb[NC], ub[NC], u[NC];
+  // Block-uniform fast path: the points of this block lie in consecutive intervals (error / interpolation points
+  // as dense as the grid, the default of fb_sweep.m:21-22): one register window per row serves all of them.
+  bool aligned = q0 + kPtsPerThread <= a.nq;
+  const int kq0 = a.KQ[q0];
+  double sq[kPtsPerThread];
+  if (aligned) {
 #pragma unroll
-  for (int k = 0; k < NS; ++k) {
-    x[k] = pchip_eval(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, k0, s);
-    lam[k] = pchip_eval(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, k0, s);
+    for (int c = 0; c < kPtsPerThread; ++c) {
+      aligned = aligned && a.KQ[q0 + c] == kq0 + c;
+      sq[c] = a.SQ[q0 + c];
+    }
+  }
+  double xw[NS][kPtsPerThread], lw[NS][kPtsPerThread];
+  if (aligned) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      pchip_run<kPtsPerThread>(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0, sq, xw[k]);
+      pchip_run<kPtsPerThread>(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0, sq, lw[k]);
+    }
+  }
+#pragma unroll
+  for (int cq = 0; cq < kPtsPerThread; ++cq) {
+  const int q = q0 + cq;
+  if (q >= a.nq) break;
+  const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
+  double x[NS], lam[NS], tu[NTU], lb[NC], ub[NC], u[NC];
+  if (aligned) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      x[k] = xw[k][cq];
+      lam[k] = lw[k][cq];
+    }
+  } else {
+    const int k0 = a.KQ[q];
+    const double s = a.SQ[q];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      x[k] = pchip_eval(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, k0, s);
+      lam[k] = pchip_eval(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, k0, s);
+    }
   }
 #pragma unroll
   for (int k = 0; k < NTU; ++k) tu[k] = a.TUQ[(size_t)q * NTU + k];
@@ -347,14 +481,15 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
     ub[c] = a.ub[c];
   }
   P::control_char(tu, x, lam, p, lb, ub, u);
-  double* dst = a.out + (a.usel ? (long long)(1 - a.usel[b]) * a.odelta : 0);
-#pragma unroll
-  for (int c = 0; c < NC; ++c) dst[((size_t)q * NC + c) * B + b] = u[c];
+  // Error-point mode: `out` holds the instance's current control at these points and is replaced in place.
+  // An instance that turns out converged (k_fbs_advance) never reads these samples again -- its x, lam, J already
+  // belong to the old control (fb_sweep.m:82) -- and one that continues takes uNew anyway (:85), so no second
+  // buffer and no per-instance select is needed: loads and stores stay coalesced.
+  double* dst = a.out;
   if (a.metric) {  // fb_sweep.m:107  abs(uNew - u) ./ (uRelTol*abs(u) + uAbsTol), max() skips NaN (:108)
-    const double* old = a.out + (long long)a.usel[b] * a.odelta;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
-      const double o = old[((size_t)q * NC + c) * B + b];
+      const double o = dst[((size_t)q * NC + c) * B + b];
       const double w = fabs(u[c] - o) / (a.relTol * fabs(o) + a.absTol);
       if (w == w) {
         wmax = any ? fmax(wmax, w) : w;
@@ -362,11 +497,11 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
       }
     }
   }
+#pragma unroll
+  for (int c = 0; c < NC; ++c) dst[((size_t)q * NC + c) * B + b] = u[c];
   }  // q
-  if (a.metric && any) {
-    atomicMax(&a.metric[b], (unsigned long long)__double_as_longlong(wmax));
-    a.anyvalid[b] = 1;
-  }
+  // partial maxima go to memory (one coalesced store per block row) and are reduced by k_fbs_advance: no atomics
+  if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? wmax : -1.0;
 }
 
 // ControlChar-side time coefficients at arbitrary times
@@ -385,15 +520,24 @@ __global__ void k_tu_at(int nq, const double* __restrict__ tq, const double* __r
 // status: 0 active, k > 0 converged at sweep k.  An active instance whose change is <= 1 keeps
 // its OLD control (final_sweep(u), :82) and freezes; otherwise it switches to the new buffer.
 // ---------------------------------------------------------------------------------------
-__global__ void k_fbs_advance(int batch, int sweep, unsigned long long* __restrict__ metric,
+__global__ void k_fbs_advance(int batch, int sweep, int nparts, const double* __restrict__ metric,
                               int* __restrict__ anyvalid, int* __restrict__ usel, int* __restrict__ status,
                               double* __restrict__ maxChange, int* __restrict__ nactive) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   bool still = false;
   if (b < batch) {
-    const double mx = anyvalid[b] ? __longlong_as_double((long long)metric[b]) : __builtin_nan("");
-    metric[b] = 0ull;  // reset for the next sweep
-    anyvalid[b] = 0;
+    (void)anyvalid;
+    double mx = -1.0;  // max over the valid (non-NaN) weighted changes, NaN if there is none (:108)
+    int q = 0;
+    for (; q + 8 <= nparts; q += 8) {  // eight independent loads in flight
+      double m[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) m[j] = metric[(size_t)(q + j) * batch + b];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) mx = fmax(mx, m[j]);
+    }
+    for (; q < nparts; ++q) mx = fmax(mx, metric[(size_t)q * batch + b]);
+    if (mx < 0.0) mx = __builtin_nan("");
     if (status[b] == 0) {
       maxChange[(size_t)(sweep - 1) * batch + b] = mx;  // the value :109 prints
       if (mx <= 1.0) {                                   // :110

@@ -32,10 +32,11 @@ static inline int hip_rc3(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
     default: return -1;                   \
   }
 
-static PchipTab make_tab(const FbsTables& t) { return PchipTab{t.n, t.TN, t.HN, t.W1, t.W2}; }
+static PchipTab make_tab(const FbsTables& t) { return PchipTab{t.n, t.TN, t.HN, t.W1, t.W2, t.IH}; }
 
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s) {
-  k_pchip_mid<<<dim3((batch + 255) / 256, t.n - 1), dim3(256), 0, s>>>(make_tab(t), nrows, ld, batch, t.TM, V, out);
+  k_pchip_mid<<<dim3((batch + 255) / 256, (t.n - 1 + kPchipRun - 1) / kPchipRun), dim3(256), 0, s>>>(make_tab(t), nrows, ld,
+                                                                                                    batch, t.TM, V, out);
   return hip_rc3(hipGetLastError());
 }
 
@@ -57,15 +58,15 @@ int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const dou
 
 template <class P>
 static void run_control_grid(const ControlGridArgs& a, hipStream_t s) {
-  k_control_grid<P><<<dim3((a.batch + 255) / 256, 2 * a.N + 1), dim3(256), 0, s>>>(a);
+  k_control_grid<P><<<dim3((a.batch + 255) / 256, (a.N + kPchipRun - 1) / kPchipRun), dim3(256), 0, s>>>(a);
 }
-int launch_control_grid(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx,
-                        const double* xmid, const double* lam, const double* lmid, double* u, const int* status,
-                        hipStream_t s) {
-  const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, lmid, u, status};
+int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
+                        const double* xmid, const double* lam, double* u, const int* status, hipStream_t s) {
+  const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, make_tab(t), t.TM, u,
+                          status};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
-    return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, 2 * g.N + 1), dim3(256), args, s);
+    return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, (g.N + kPchipRun - 1) / kPchipRun), dim3(256), args, s);
   }
   if (p.functor != Functor::Logistic) return -1;
   OCS_DISPATCH_LOGISTIC2(p.nS, run_control_grid<P>(a, s));
@@ -78,7 +79,7 @@ static void run_control_pts(const ControlPtsArgs& a, hipStream_t s) {
 }
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
-                       const int* usel, long long odelta, unsigned long long* metric, int* anyvalid, double relTol,
+                       const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
                        double absTol, hipStream_t s) {
   const ControlPtsArgs a{nq, batch, make_tab(t), KQ, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out,
                          usel, odelta, metric, anyvalid, relTol, absTol};
@@ -107,9 +108,10 @@ int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hi
   return hip_rc3(hipGetLastError());
 }
 
-int launch_fbs_advance(int batch, int sweep, unsigned long long* metric, int* anyvalid, int* usel, int* status,
+int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
+int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
                        double* maxChange, int* nactive, hipStream_t s) {
-  k_fbs_advance<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, sweep, metric, anyvalid, usel, status,
+  k_fbs_advance<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, sweep, nparts, metric, anyvalid, usel, status,
                                                                  maxChange, nactive);
   return hip_rc3(hipGetLastError());
 }

@@ -117,19 +117,20 @@ struct FbsTables {   // pchip node tables of an integrator grid, device pointers
   const double* W1;  // [n] interior slope weights (entries 1..n-2 used)
   const double* W2;
   const double* TM;  // [n-1] interval midpoints
+  const double* IH;  // [n-1] reciprocal spacings
 };
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* usel, long long udelta, double* lam, hipStream_t s);
-int launch_control_grid(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx,
-                        const double* xmid, const double* lam, const double* lmid, double* u, const int* status,
-                        hipStream_t s);
+int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
+                        const double* xmid, const double* lam, double* u, const int* status, hipStream_t s);
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
-                       const int* usel, long long odelta, unsigned long long* metric, int* anyvalid, double relTol,
+                       const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
                        double absTol, hipStream_t s);
 int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
-int launch_fbs_advance(int batch, int sweep, unsigned long long* metric, int* anyvalid, int* usel, int* status,
+int control_pts_parts(int nq);  // rows of the partial-maximum array `metric` [parts][B] that launch_control_pts fills
+int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
                        double* maxChange, int* nactive, hipStream_t s);
 
 // registry queries (host)

@@ -31,3 +31,18 @@ def vectorInterpolant(x, v, interpType):
 def heval(func, tspan, components):
     """functions/heval.m:1-6 (components are 0-based here)."""
     return func(tspan)[components, :]
+
+
+def linspace(d1, d2, n=100):
+    """MATLAB linspace(d1, d2, n): d1 + (0:n-1)*(d2-d1)/(n-1) with both end points pinned.  The reference builds
+    tspan and fb_sweep's error / interpolation points (fb_sweep.m:69-70) with it; numpy.linspace rounds
+    differently (start + k*step), so grids meant to coincide with those points should come from here."""
+    n = int(n)
+    if n <= 0:
+        return np.empty(0)
+    if n == 1:
+        return np.array([float(d2)])
+    k = np.arange(n, dtype=np.float64)
+    out = d1 + (k * (d2 - d1)) / (n - 1)
+    out[0], out[-1] = d1, d2
+    return out
