@@ -39,8 +39,11 @@ int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s);
 enum Mapping : int { MAP_AUTO = 0, MAP_LANE = 1, MAP_ROWSPLIT = 2, MAP_PIPELINE = 3 };
 bool pipeline_supported(Functor f, int nS, int nC);
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward);  // nSTEPS multiple of the block, batch of the tile
+int pipeline_block_steps();  // the pipeline kernels take whole blocks of this many steps
+// pend0: optional [B], the k1 half of column 2N of dJdu when the steps above N were integrated by another kernel
 int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
-                       const double* lamT, double* lam, double* dJdu, double* lam0, hipStream_t s);
+                       const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
+                       hipStream_t s);
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, hipStream_t s);
 bool rowsplit_supported(Functor f, int nS, int nC);

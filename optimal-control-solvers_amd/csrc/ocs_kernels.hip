@@ -150,11 +150,21 @@ static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
 // LDS each) fit on the chip in at most two rounds; row-split while the lane mapping would leave most
 // SIMDs idle; beyond that the lane mapping has the fewest instructions per trajectory and the
 // passes turn HBM-bound anyway.
-static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested, bool plain, bool backward) {
+// The pipeline kernels take whole blocks of 8 steps.  Other step counts are split: the first 8*floor(N/8) steps
+// go through the pipeline kernel, the remaining (< 8) through the lane kernel, which continues from / hands over
+// the boundary column (running objective, lamT, the k1 half of the boundary column of dJdu), so the result is
+// the one-kernel result bit for bit.  splits(): 0 = no pipeline, else the number of pipeline steps.
+static int pipeline_steps(const ProblemDesc& p, int N, int batch, bool backward) {
+  const int D = pipeline_block_steps(), N1 = (N / D) * D;
+  if (!pipeline_supported(p.functor, p.nS, p.nC) || N1 < D || !pipeline_shape_ok(p.nS, N1, batch, backward)) return 0;
+  return N1;
+}
+// boundary: the caller's output arrays can carry the hand-over column of a split pass (x forward, lam backward)
+static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested, bool plain, bool backward,
+                          bool boundary) {
   if (requested != MAP_AUTO) return requested;
-  if (plain && pipeline_supported(p.functor, p.nS, p.nC) && pipeline_shape_ok(p.nS, N, batch, backward) &&
-      batch / (64 / p.nS) <= 512)
-    return MAP_PIPELINE;
+  const int N1 = plain ? pipeline_steps(p, N, batch, backward) : 0;
+  if (N1 > 0 && (N1 == N || boundary) && batch / (64 / p.nS) <= 512) return MAP_PIPELINE;
   if (plain && rowsplit_supported(p.functor, p.nS, p.nC) && batch <= 8192) return MAP_ROWSPLIT;
   return MAP_LANE;
 }
@@ -163,17 +173,28 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
   if (p.functor == Functor::LQ) return launch_forward_lq(p, g, batch, x0, u, x, J, o, s);
   const bool plain = !o.uconst && !o.Jadd && !o.usel;
-  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, false);
+  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, false, x != nullptr);
   if (map == MAP_PIPELINE) {
-    if (!plain || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
-    return launch_forward_pl(p, g, batch, x0, u, x, J, s);
+    const int N1 = plain ? pipeline_steps(p, g.N, batch, false) : 0;
+    if (N1 == 0 || (N1 < g.N && !x)) return -1;  // the split needs the boundary column in memory
+    GridDesc g1 = g;
+    g1.N = N1;
+    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, s);
+    if (rc || N1 == g.N) return rc;
+    // remaining steps N1 .. N-1 on the lane kernel, continuing from column N1 (state rows and running objective)
+    const size_t col = (size_t)(p.nS + 1) * batch, ucol = (size_t)p.nC * batch;
+    double* xb = x + (size_t)N1 * col;
+    const FwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
+                    p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, nullptr, 0, xb + (size_t)p.nS * batch};
+    OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, false, s));
+    return hip_rc(hipGetLastError());
   }
   if (map == MAP_ROWSPLIT) {
     if (!plain || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;
     return launch_forward_rs(p, g, batch, x0, u, x, J, s);
   }
   if (o.uconst && !x) return -1;
-  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.usel, o.udelta};
+  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.usel, o.udelta, nullptr};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     const int kid = o.uconst ? UK_FWD_UCONST : (x ? UK_FWD_X : UK_FWD_J);
@@ -199,10 +220,25 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
   if (p.functor == Functor::LQ) return launch_backward_lq(p, g, batch, xck, u, lamT, lam, dJdu, o, s);
   const bool plain = !o.uconst && !o.usel;
-  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, true);
+  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, true, lam != nullptr);
   if (map == MAP_PIPELINE) {
-    if (!plain || !pipeline_supported(p.functor, p.nS, p.nC)) return -1;
-    return launch_backward_pl(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
+    const int N1 = plain ? pipeline_steps(p, g.N, batch, true) : 0;
+    if (N1 == 0 || (N1 < g.N && !lam)) return -1;  // the split hands lam(:, N1) over through memory
+    if (N1 == g.N) return launch_backward_pl(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, nullptr, s);
+    // steps N-1 .. N1 first, on the lane kernel: lam columns N1..N, dJdu columns 2 N1 .. 2 N (column 2 N1 holds the
+    // k1 half only, RK4Integrator.m:108-112) ...
+    const size_t col = (size_t)(p.nS + 1) * batch, ucol = (size_t)p.nC * batch;
+    double* lamb = lam + (size_t)N1 * col;
+    double* db = dJdu ? dJdu + (size_t)(2 * N1) * ucol : nullptr;
+    const BwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
+                    p.pmask, xck + (size_t)N1 * col, u + (size_t)(2 * N1) * ucol, lamT, lamb, db, nullptr, nullptr, 0};
+    OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, false, s));
+    int rc = hip_rc(hipGetLastError());
+    if (rc) return rc;
+    // ... then the whole blocks below, started from lam(:, N1) and adding their k4 half to column 2 N1
+    GridDesc g1 = g;
+    g1.N = N1;
+    return launch_backward_pl(p, g1, batch, xck, u, lamb, lam, dJdu, o.lam0, db, s);
   }
   if (map == MAP_ROWSPLIT) {
     if (!plain || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;

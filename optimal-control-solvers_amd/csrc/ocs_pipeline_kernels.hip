@@ -333,6 +333,8 @@ struct BwdArgsPL {
   double* dJdu;
   double* lam0;
   long long* dbg;  // diagnostic build only
+  const double* pend0;  // optional [B]: the k1 half of the last column (2N) when the steps above N were done by
+                        // another kernel (a pass split at a multiple of the block length); default 0
 };
 
 template <class P, bool OUT_LAM, bool OUT_DJDU>
@@ -520,7 +522,8 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   } else {
     // ---------------- D: dJdu columns ----------------
     double* dp = a.dJdu + (size_t)(2 * N) * B + b;  // dJdu(2N+1), walks down
-    double cunext = rp.cw * a.u[(size_t)(2 * N) * B + b], pend = 0.0;
+    double cunext = rp.cw * a.u[(size_t)(2 * N) * B + b];
+    double pend = (a.pend0 && r == 0) ? a.pend0[b] : 0.0;  // summed over the rows of a trajectory below
     long long tb = 0, tc = 0;
     for (int k = 0; k <= nb + 1; ++k) {
       const long long t0 = PL_T();
@@ -598,6 +601,7 @@ bool pipeline_shape_ok(int nS, int N, int batch, bool backward) {
   (void)backward;
   return N >= D && N % D == 0 && batch % TPW == 0;
 }
+int pipeline_block_steps() { return 8; }
 
 template <class P>
 static void run_forward_pl(const FwdArgsPL& a, hipStream_t s) {
@@ -657,9 +661,10 @@ static void run_backward_pl(const BwdArgsPL& a, hipStream_t s) {
     k_backward_pl<P, false, true><<<grid, block, 0, s>>>(a);
 }
 int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
-                       const double* lamT, double* lam, double* dJdu, double* lam0, hipStream_t s) {
+                       const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
+                       hipStream_t s) {
   if (!pipeline_shape_ok(p.nS, g.N, batch, true) || (!lam && !dJdu)) return -1;
-  BwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, lam0, nullptr};
+  BwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, lam0, nullptr, pend0};
 #ifdef OCS_PL_STAMPS
   static long long* dbgb = nullptr;
   const int nwg = batch / (64 / p.nS);

@@ -62,6 +62,8 @@ struct FwdArgs {
   const double* Jadd;   // optional [B]: J = Jadd + x(end,end)  (RK4InfiniteIntegrator.m:23  J = J1 + J2)
   const int* usel;      // optional [B]: trajectory b reads its controls from u + usel[b] * udelta
   long long udelta;     //              (fb_sweep keeps the old and the new control in two buffers)
+  const double* yc0;    // optional [B]: running objective at the first node (a pass continued from another
+                        //               kernel's last column; default 0, RK4Integrator.m:33)
 };
 
 // Lanes past the end of the batch are clamped onto the last trajectory: they recompute it and
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
 
   const double warm = warm_table(a.REC, (size_t)N * rec_stride(NTC));
 
-  double y[NS], yc = 0.0;  // xK(:,1,1) = [x0; 0]   :33
+  double y[NS], yc = a.yc0 ? a.yc0[b] : 0.0;  // xK(:,1,1) = [x0; 0]   :33
 #pragma unroll
   for (int k = 0; k < NS; ++k) y[k] = a.x0[(size_t)k * B + b];
   // All per-trajectory arrays are walked with one pointer that advances by B doubles per row:
@@ -94,7 +96,7 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
       *xo = y[k];
       xo += B;
     }
-    *xo = 0.0;
+    *xo = yc;
     xo += B;
   }
 

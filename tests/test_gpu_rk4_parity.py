@@ -90,7 +90,8 @@ def test_states_and_adjoints_match_oracle(ocs, oracle, nS, N, batch, T):
 
 @pytest.mark.parametrize("nS,N,batch,T", [(4, 200, 130, 10.0), (2, 3, 64, 0.2), (2, 9, 129, 0.5), (4, 1, 5, 0.05),
                                           (4, 37, 1, 2.0), (2, 1000, 40, 10.0), (4, 8, 17, 0.4), (4, 16, 64, 0.8), (4, 48, 32, 2.0), (2, 8, 32, 0.4), (2, 40, 96, 2.0), (4, 1008, 16, 10.0),
-                                          (2, 17, 33, 0.8), (4, 24, 3, 1.0)])
+                                          (2, 17, 33, 0.8), (4, 24, 3, 1.0), (4, 1003, 16, 10.0), (2, 17, 32, 0.8),
+                                          (4, 12, 32, 0.6), (2, 15, 64, 0.7), (4, 7, 16, 0.3)])
 @pytest.mark.parametrize("mapping", ["lane", "rowsplit", "pipeline"])
 def test_both_mappings_match_oracle(ocs, oracle, nS, N, batch, T, mapping):
     # the row-split kernels (one state row per lane) must give the same answers as lane-per-trajectory,
@@ -100,9 +101,11 @@ def test_both_mappings_match_oracle(ocs, oracle, nS, N, batch, T, mapping):
     pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
     g = ocs.RK4Integrator(tspan).set_mapping(mapping)
     D, tile = 8, 64 // nS
-    if mapping == "pipeline" and (N % D != 0 or batch % tile != 0):
-        # the wave-specialised kernels hand off in blocks of D steps over tiles of 64/nS trajectories:
-        # other shapes are refused when forced (automatic selection falls back), never mis-computed
+    if mapping == "pipeline" and (N < D or batch % tile != 0):
+        # the wave-specialised kernels hand off in blocks of D steps over tiles of 64/nS trajectories; a step
+        # count that is not a multiple of D is split (whole blocks on the pipeline kernel, the last < D steps
+        # on the lane kernel, handing over the boundary column).  Fewer than D steps or a ragged tile are
+        # refused when forced (automatic selection falls back), never mis-computed
         with pytest.raises(ocs.OcsError) as e:
             g.compute_states(pg, x0, u)
         assert e.value.code == -6
