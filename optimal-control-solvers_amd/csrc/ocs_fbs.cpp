@@ -17,14 +17,14 @@ struct ocs_fbs_state {
   unsigned long long tu_version = 0;
   const ocs_problem_s* tu_prob = nullptr;
   // work arrays
-  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid;
+  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid, dump;
 };
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
   if (!s) return;
   DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->IH, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
                     &s->TI, &s->TUI, &s->xaug, &s->xmid, &s->lam, &s->lmid, &s->ugrid, &s->uerr, &s->uint_, &s->J,
-                    &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage, &s->metric, &s->anyvalid};
+                    &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage, &s->metric, &s->anyvalid, &s->dump};
   for (DevBuf* b : bufs) b->release();
   delete s;
 }
@@ -194,6 +194,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   OCS_TRY(f->ugrid.ensure(sizeof(double) * ugridN));
   OCS_TRY(f->uerr.ensure(sizeof(double) * uerrN));
   OCS_TRY(f->usel.ensure(sizeof(int) * B));
+  OCS_TRY(f->dump.ensure(sizeof(double) * B));
   OCS_TRY(f->nactive.ensure(sizeof(int)));
   const int nparts = control_pts_parts(nE);
   OCS_TRY(f->metric.ensure(sizeof(double) * (size_t)nparts * B));
@@ -221,9 +222,14 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   int nactive = batch;
   for (int sweep = 1; sweep <= opt->nSWEEPS && nactive > 0; ++sweep) {  // :79
     // uNew = sweep(u): compute_x_lam (:95) ...
-    LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, FwdOpts(), s));
+    // instances that converged in an earlier sweep are integrated along but store nothing: their x, lam, J stay
+    // those of the sweep they converged in (final_sweep(u), :82)
+    FwdOpts fo;
+    fo.frozen = status;
+    fo.dump = f->dump.d();
+    LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
     LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
-    LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), nullptr, 0, lam, s));
+    LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), status, f->dump.d(), lam, s));
     // ... uNew = ControlChar(t, x(t), lam(t)) (:96) on the error points, with check_convergence(uNew, u)
     // (:81, :99-115) folded in
     HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));

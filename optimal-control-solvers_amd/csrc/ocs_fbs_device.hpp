@@ -172,8 +172,8 @@ struct CostateArgs {
   int ldx;
   const double* xmid;  // [N][nS][B]
   const double* u;     // [2N+1][nC][B]
-  const int* usel;
-  long long udelta;
+  const int* frozen;   // optional [B]: instances with frozen[b] != 0 (converged in an earlier sweep) store nothing
+  double* dump;        // [B] scratch for their stores
   double* lam;         // [N+1][nS][B]
 };
 
@@ -192,16 +192,19 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
   const double* xp = a.x + b;
   const double* mp = a.xmid + b;
   const double* up = a.u + b;
-  if (a.usel) up += (long long)a.usel[b] * a.udelta;
-  double* lp = a.lam + b;
+  // lam is walked downwards with a per-lane row stride; a frozen instance has stride 0 on a scratch double
+  const bool fz = a.frozen && a.frozen[b] != 0;
+  const size_t lrow = fz ? 0 : B;
+  double* lp = fz ? a.dump + b : a.lam + b;
 
   double l[NS], xB[NS], uB[NC];
 #pragma unroll
   for (int k = 0; k < NS; ++k) {
     l[k] = 0.0;  // lam0 = 0*x0   compute_x_lam.m:4
     xB[k] = xp[((size_t)N * a.ldx + k) * B];
-    lp[((size_t)N * NS + k) * B] = 0.0;
+    lp[((size_t)N * NS + k) * lrow] = 0.0;
   }
+  double* lq = lp + (size_t)N * NS * lrow;  // column i + 1 of lam; steps run i = N-1 .. 0
 #pragma unroll
   for (int c = 0; c < NC; ++c) uB[c] = up[((size_t)(2 * N) * NC + c) * B];
 
@@ -242,11 +245,13 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       l[k] = __builtin_fma(-r.h6, __builtin_fma(2.0, k3[k], __builtin_fma(2.0, k2[k], k1[k])) + k4[k], l[k]);
-      lp[((size_t)i * NS + k) * B] = l[k];
+      (lq - NS * lrow)[k * lrow] = l[k];
       xB[k] = cxA[k];
     }
 #pragma unroll
     for (int c = 0; c < NC; ++c) uB[c] = cuA[c];
+    lq -= NS * lrow;
+    (void)i;
   };
   auto next_rec = [&]() OCS_INLINE {
     const Rec r = rq[0];

@@ -45,8 +45,9 @@ static void run_costate(const CostateArgs& a, hipStream_t s) {
   k_costate<P, 4><<<dim3((a.batch + 63) / 64), dim3(64), 0, s>>>(a);
 }
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
-                   const double* u, const int* usel, long long udelta, double* lam, hipStream_t s) {
-  const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, usel, udelta, lam};
+                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s) {
+  if (frozen && !dump) return -1;
+  const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_COSTATE, dim3((batch + 63) / 64), dim3(64), args, s);

@@ -45,7 +45,7 @@ int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const
                        const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
                        hipStream_t s);
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                      double* x, double* J, hipStream_t s);
+                      double* x, double* J, const int* frozen, double* dump, hipStream_t s);
 bool rowsplit_supported(Functor f, int nS, int nC);
 int launch_forward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, hipStream_t s);
@@ -68,15 +68,13 @@ struct FwdOpts {
   int mapping = MAP_AUTO;
   bool uconst = false;          // u is a device [nC] vector shared by all grid points and trajectories
   const double* Jadd = nullptr; // J = Jadd + x(end,end)
-  const int* usel = nullptr;    // per-trajectory control buffer select (fb_sweep)
-  long long udelta = 0;
+  const int* frozen = nullptr;  // [B]: trajectories with frozen[b] != 0 store nothing (fb_sweep: converged instances)
+  double* dump = nullptr;       // [B] scratch the stores of frozen trajectories go to
 };
 struct BwdOpts {
   int mapping = MAP_AUTO;
   bool uconst = false;
   double* lam0 = nullptr;       // [nAug][B]: lam(:,1)
-  const int* usel = nullptr;
-  long long udelta = 0;
 };
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s);
@@ -124,7 +122,7 @@ struct FbsTables {   // pchip node tables of an integrator grid, device pointers
 };
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
-                   const double* u, const int* usel, long long udelta, double* lam, hipStream_t s);
+                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, hipStream_t s);
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,

@@ -172,29 +172,30 @@ static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested,
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
   if (p.functor == Functor::LQ) return launch_forward_lq(p, g, batch, x0, u, x, J, o, s);
-  const bool plain = !o.uconst && !o.Jadd && !o.usel;
-  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, false, x != nullptr);
+  const bool plain = !o.uconst && !o.Jadd;
+  int map = choose_mapping(p, g.N, batch, o.mapping, plain, false, x != nullptr);
+  if (map == MAP_ROWSPLIT && o.frozen && o.mapping == MAP_AUTO) map = MAP_LANE;  // no frozen lanes in that kernel
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, false) : 0;
     if (N1 == 0 || (N1 < g.N && !x)) return -1;  // the split needs the boundary column in memory
     GridDesc g1 = g;
     g1.N = N1;
-    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, s);
+    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, s);
     if (rc || N1 == g.N) return rc;
     // remaining steps N1 .. N-1 on the lane kernel, continuing from column N1 (state rows and running objective)
     const size_t col = (size_t)(p.nS + 1) * batch, ucol = (size_t)p.nC * batch;
     double* xb = x + (size_t)N1 * col;
     const FwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
-                    p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, nullptr, 0, xb + (size_t)p.nS * batch};
+                    p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, o.frozen, o.dump, xb + (size_t)p.nS * batch};
     OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, false, s));
     return hip_rc(hipGetLastError());
   }
   if (map == MAP_ROWSPLIT) {
-    if (!plain || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;
+    if (!plain || o.frozen || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;
     return launch_forward_rs(p, g, batch, x0, u, x, J, s);
   }
   if (o.uconst && !x) return -1;
-  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.usel, o.udelta, nullptr};
+  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.frozen, o.dump, nullptr};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     const int kid = o.uconst ? UK_FWD_UCONST : (x ? UK_FWD_X : UK_FWD_J);
@@ -219,7 +220,7 @@ static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
 int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
   if (p.functor == Functor::LQ) return launch_backward_lq(p, g, batch, xck, u, lamT, lam, dJdu, o, s);
-  const bool plain = !o.uconst && !o.usel;
+  const bool plain = !o.uconst;
   const int map = choose_mapping(p, g.N, batch, o.mapping, plain, true, lam != nullptr);
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, true) : 0;
@@ -231,7 +232,7 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
     double* lamb = lam + (size_t)N1 * col;
     double* db = dJdu ? dJdu + (size_t)(2 * N1) * ucol : nullptr;
     const BwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
-                    p.pmask, xck + (size_t)N1 * col, u + (size_t)(2 * N1) * ucol, lamT, lamb, db, nullptr, nullptr, 0};
+                    p.pmask, xck + (size_t)N1 * col, u + (size_t)(2 * N1) * ucol, lamT, lamb, db, nullptr};
     OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, false, s));
     int rc = hip_rc(hipGetLastError());
     if (rc) return rc;
@@ -245,7 +246,7 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
     return launch_backward_rs(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, s);
   }
   if (o.uconst ? (lam || dJdu || !o.lam0) : (!lam && !dJdu)) return -1;
-  const BwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, o.lam0, o.usel, o.udelta};
+  const BwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, o.lam0};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     const int kid = o.uconst ? UK_BWD_UCONST : (lam && dJdu ? UK_BWD_LAM_DJDU : (lam ? UK_BWD_LAM : UK_BWD_DJDU));

@@ -1067,7 +1067,7 @@ static void run_lq_forward(const LQArgs& a, bool uconst, hipStream_t s) {
 }
 int launch_forward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, const FwdOpts& o, hipStream_t s) {
-  if (!lq_supported(p.nS, p.nC) || p.pmask || o.usel || (o.uconst && !x)) return -1;
+  if (!lq_supported(p.nS, p.nC) || p.pmask || o.frozen || (o.uconst && !x)) return -1;
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
   a.x0 = x0; a.u = u; a.x = x; a.J = J; a.Jadd = o.Jadd;
@@ -1118,7 +1118,7 @@ static void run_lq_backward(const LQArgs& a, bool uconst, hipStream_t s) {
 }
 int launch_backward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                        const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
-  if (!lq_supported(p.nS, p.nC) || p.pmask || o.usel) return -1;
+  if (!lq_supported(p.nS, p.nC) || p.pmask) return -1;
   if (o.uconst ? (lam || dJdu || !o.lam0) : (!lam && !dJdu)) return -1;
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;

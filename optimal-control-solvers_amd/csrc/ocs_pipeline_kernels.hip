@@ -115,6 +115,8 @@ struct FwdArgsPL {
   double* x;
   double* J;
   long long* dbg;  // diagnostic build (-DOCS_PL_STAMPS) only: per-workgroup cycle sums; nullptr otherwise
+  const int* frozen;  // optional [B]: trajectories with frozen[b] != 0 store nothing (as in FwdArgs)
+  double* dump;       // [B] scratch for their stores
 };
 
 // ---------------------------------------------------------------------------------------
@@ -184,13 +186,15 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
     const typename P::RowPar rp = P::load_row([&](int k) OCS_INLINE {
       return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
     }, r);
-    const size_t colB = (size_t)NAUG * B;
+    // a frozen trajectory writes every value to one scratch double (pointer stride 0): no branch around stores
+    const bool fz = a.frozen && a.frozen[b] != 0;
+    const size_t colB = fz ? 0 : (size_t)NAUG * B;
     const double u0 = a.u[b];
     if (wave == 1) {
       // ---------------- S: state recursion ----------------
       double y = a.x0[(size_t)r * B + b];
       double uprev = u0;
-      double* xs = a.x + (size_t)r * B + b;
+      double* xs = fz ? a.dump + b : a.x + (size_t)r * B + b;
       if (OUT_X) *xs = y;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
@@ -253,7 +257,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       // pc += W_A q1 + W_M (q2 + q3) + W_B q4 with the quadrature weights of the record table
       // (W_A = h/6 e^{-r t_A}, ...): the same sum as h/6 (F1 + 2 F2 + 2 F3 + F4) of the cost row.
       double pc = 0.0, uprev2 = u0 * u0;
-      double* xc = a.x + (size_t)G * B + b;
+      double* xc = fz ? a.dump + b : a.x + (size_t)G * B + b;
       if (OUT_X) *xc = 0.0;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
@@ -306,7 +310,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       }
 #endif
       (void)tb; (void)tc;
-      a.J[b] = group_sum_pl<G>(pc);
+      const double Jt = group_sum_pl<G>(pc);
+      if (!fz) a.J[b] = Jt;
     }
   }
 }
@@ -613,9 +618,9 @@ static void run_forward_pl(const FwdArgsPL& a, hipStream_t s) {
     k_forward_pl<P, false><<<grid, block, 0, s>>>(a);
 }
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                      double* x, double* J, hipStream_t s) {
-  if (!pipeline_shape_ok(p.nS, g.N, batch, false)) return -1;
-  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr};
+                      double* x, double* J, const int* frozen, double* dump, hipStream_t s) {
+  if (!pipeline_shape_ok(p.nS, g.N, batch, false) || (frozen && !dump)) return -1;
+  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump};
 #ifdef OCS_PL_STAMPS
   static long long* dbg = nullptr;
   const int nwg = batch / (64 / p.nS);

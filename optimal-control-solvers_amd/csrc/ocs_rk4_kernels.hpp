@@ -60,8 +60,8 @@ struct FwdArgs {
   double* x;
   double* J;
   const double* Jadd;   // optional [B]: J = Jadd + x(end,end)  (RK4InfiniteIntegrator.m:23  J = J1 + J2)
-  const int* usel;      // optional [B]: trajectory b reads its controls from u + usel[b] * udelta
-  long long udelta;     //              (fb_sweep keeps the old and the new control in two buffers)
+  const int* frozen;    // optional [B]: a trajectory with frozen[b] != 0 is integrated but stores nothing (fb_sweep:
+  double* dump;         //   a converged instance keeps the x, J of the sweep it converged in); its stores go to dump[b]
   const double* yc0;    // optional [B]: running objective at the first node (a pass continued from another
                         //               kernel's last column; default 0, RK4Integrator.m:33)
 };
@@ -89,15 +89,18 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
   for (int k = 0; k < NS; ++k) y[k] = a.x0[(size_t)k * B + b];
   // All per-trajectory arrays are walked with one pointer that advances by B doubles per row:
   // rows of consecutive time points are B apart, so no per-row offset arithmetic is needed.
-  double* xo = a.x + b;
+  // frozen lanes write every row to one scratch double (pointer stride 0): no branch around the stores
+  const bool fz = a.frozen && a.frozen[b] != 0;
+  const size_t xstep = fz ? 0 : B;
+  double* xo = fz ? a.dump + b : a.x + b;
   if (OUT_X) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
       *xo = y[k];
-      xo += B;
+      xo += xstep;
     }
     *xo = yc;
-    xo += B;
+    xo += xstep;
   }
 
   const double* up = a.u;  // walks u(:,j) row by row
@@ -107,7 +110,6 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
     for (int c = 0; c < NC; ++c) uprev[c] = PSU(a.u)[c];
   } else {
     up += b;
-    if (a.usel) up += (long long)a.usel[b] * a.udelta;
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
       uprev[c] = *up;
@@ -136,10 +138,10 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         *xo = y[k];
-        xo += B;
+        xo += xstep;
       }
       *xo = yc;
-      xo += B;
+      xo += xstep;
     }
   };
 
@@ -189,7 +191,7 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
       const Rec cur = next_rec();
       step(cur, uprev, uprev, uprev);
     }
-    a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;
+    if (!fz) a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;
     if (warm == 1.234567e300) a.J[b] = warm;
     return;
   }
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
 #pragma unroll
     for (int cc = 0; cc < NC; ++cc) uprev[cc] = uB[cc];
   }
-  a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;  // J = x(end,end)   :55
+  if (!fz) a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;  // J = x(end,end)   :55
   if (warm == 1.234567e300) a.J[b] = warm;  // never true for a table of step sizes; keeps the sweep alive
 }
 
@@ -239,8 +241,6 @@ struct BwdArgs {
   double* lam;
   double* dJdu;
   double* lam0;         // optional [nAug][B]: lam(:,1) only (RK4InfiniteIntegrator.m:29, single_shooting.m:149)
-  const int* usel;      // as in FwdArgs
-  long long udelta;
 };
 
 template <class P, int CH, int PF, bool OUT_LAM, bool OUT_DJDU, bool UCONST>
@@ -273,7 +273,6 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
   const double* up = a.u;
   if (!UCONST) {
     up += b + ((size_t)(2 * N + 1) * NC) * B;  // one past u(end,2N+1)
-    if (a.usel) up += (long long)a.usel[b] * a.udelta;
   }
   const double* xp = a.xck + b + ((size_t)N * NAUG) * B;        // x(1,N+1): one past x(end,N)
   double* dp = a.dJdu + b + ((size_t)(2 * N + 1) * NC) * B;     // one past dJdu(end,2N+1)
