@@ -189,6 +189,8 @@ typedef struct ocs_fbs_options {
   int nSWEEPS;     /* :20 */
   int nERROR_PTS;  /* :21 */
   int nINTERP_PTS; /* :22 */
+  int fused_update_off; /* build option, default 0: with the error points on the grid nodes the costate pass, the control
+                           update and the convergence metric run as one kernel; 1 keeps them separate (same results) */
 } ocs_fbs_options;
 int ocs_fbs_default_options(ocs_fbs_options *o);
 /* [x, lam(, J)] = compute_x_lam(_J)(prob, x0, tspan, u, RelTol, AbsTol)   compute_x_lam.m:1-19, compute_x_lam_J.m:1-21

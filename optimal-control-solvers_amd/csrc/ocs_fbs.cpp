@@ -13,6 +13,7 @@ struct ocs_fbs_state {
   bool tables = false;
   // query-point tables (error points / interp points), rebuilt when the options change
   int nerr = 0, nint = 0;
+  bool err_on_nodes = false;  // the error points are the grid nodes (the default on a linspace tspan)
   DevBuf KE, SE, TE, TUE, KI, SI, TI, TUI;
   unsigned long long tu_version = 0;
   const ocs_problem_s* tu_prob = nullptr;
@@ -79,7 +80,8 @@ static FbsTables tabs(const ocs_integrator_s* g) {
 }
 
 // interval index and local coordinate of query points linspace(T0, TF, nq)
-static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBuf& T) {
+// *on_nodes (optional): the query points are exactly the grid nodes, in order
+static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBuf& T, bool* on_nodes = nullptr) {
   const int n = g->N + 1;
   std::vector<double> q, tn(n), s(nq);
   std::vector<int> k(nq);
@@ -103,6 +105,11 @@ static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBu
     k[j] = lo;
     s[j] = q[j] - tn[lo];
   }
+  if (on_nodes) {
+    bool same = nq == n;
+    for (int j = 0; same && j < n; ++j) same = q[j] == tn[j];
+    *on_nodes = same;
+  }
   OCS_TRY(upload(K, k.data(), sizeof(int) * nq));
   OCS_TRY(upload(S, s.data(), sizeof(double) * nq));
   OCS_TRY(upload(T, q.data(), sizeof(double) * nq));
@@ -118,6 +125,7 @@ int ocs_fbs_default_options(ocs_fbs_options* o) {
   o->nSWEEPS = 50;        // :20
   o->nERROR_PTS = 1001;   // :21
   o->nINTERP_PTS = 1001;  // :22
+  o->fused_update_off = 0;
   return OCS_OK;
 }
 
@@ -172,7 +180,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const int ntu = std::max(1, functor_ntu(p->functor, p->nS));
   bool newpts = false;
   if (f->nerr != nE) {
-    OCS_TRY(build_points(g, nE, f->KE, f->SE, f->TE));
+    OCS_TRY(build_points(g, nE, f->KE, f->SE, f->TE, &f->err_on_nodes));
     f->nerr = nE;
     newpts = true;
   }
@@ -196,7 +204,11 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   OCS_TRY(f->usel.ensure(sizeof(int) * B));
   OCS_TRY(f->dump.ensure(sizeof(double) * B));
   OCS_TRY(f->nactive.ensure(sizeof(int)));
-  const int nparts = control_pts_parts(nE);
+  // Error points on the grid nodes and the default start: the control at the error points is the node samples of the
+  // grid control, so the weighted change is taken while the grid control is replaced (one kernel, one pass over x and
+  // lam) instead of in a separate error-point kernel with its own copy of the control.
+  const bool fusedup = f->err_on_nodes && !u0grid && opt->fused_update_off == 0;
+  const int nparts = fusedup ? control_grid_parts(N) : control_pts_parts(nE);
   OCS_TRY(f->metric.ensure(sizeof(double) * (size_t)nparts * B));
   OCS_TRY(f->anyvalid.ensure(sizeof(int) * B));
   double* mc = maxChange;
@@ -229,10 +241,23 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     fo.dump = f->dump.d();
     LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
     LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
+    HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));
+    if (fusedup) {
+      // costate (:95); uNew = ControlChar(t, x(t), lam(t)) on the grid, in place (:96, :85), with the weighted change at
+      // the nodes (:107) folded in.  A just-converged instance takes uNew as well, but it is frozen from now on: its
+      // x, lam, J are the ones computed above from the old control, which is what final_sweep(u) returns (:82).
+      LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), status, f->dump.d(), lam, s));
+      LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, f->xmid.d(), lam, f->ugrid.d(), status, f->metric.d(),
+                                     opt->uRelTol, opt->uAbsTol, s));
+      LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
+                                    mc, (int*)f->nactive.p, s));
+      HIP_TRY(hipMemcpyAsync(&nactive, f->nactive.p, sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipStreamSynchronize(s));
+      continue;
+    }
     LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), status, f->dump.d(), lam, s));
     // ... uNew = ControlChar(t, x(t), lam(t)) (:96) on the error points, with check_convergence(uNew, u)
     // (:81, :99-115) folded in
-    HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));
     LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
                                   f->uerr.d(), usel, (long long)uerrN, f->metric.d(),
                                   (int*)f->anyvalid.p, opt->uRelTol, opt->uAbsTol, s));
@@ -241,7 +266,8 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     // u = uNew (:85) on the integrator grid, only for the instances that continue: a converged instance
     // keeps its OLD control, which is what final_sweep(u) integrates (:82)
     // (lam's pchip midpoints are formed inside the kernel)
-    LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, f->xmid.d(), lam, f->ugrid.d(), status, s));
+    LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, f->xmid.d(), lam, f->ugrid.d(), status, nullptr, 0.0, 0.0,
+                                   s));
     HIP_TRY(hipMemcpyAsync(&nactive, f->nactive.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }

@@ -70,15 +70,18 @@ __device__ static inline double pchip_eval(const PchipTab& T, const double* V, s
 
 // interior slope from the two neighbouring secants: pchip_interior with one division less -- of del0/dmax and
 // del1/dmax one is exactly +-1 and the other is +-(dmin/dmax), so the denominator is bit-identical
+// Branch-free: lanes whose secants do not have the same strict sign compute a discarded quotient (possibly 0/0)
+// and select 0; divergent branches around two divisions cost more than the divisions.
 __device__ static inline double pchip_interior2(double del0, double del1, double w1, double w2) {
-  if (dsgn(del0) * dsgn(del1) <= 0) return 0.0;
+  const bool same = (del0 > 0.0 && del1 > 0.0) || (del0 < 0.0 && del1 < 0.0);
   const double a0 = fabs(del0), a1 = fabs(del1);
   const double sg = del0 > 0.0 ? 1.0 : -1.0;
   const bool first = a0 >= a1;  // dmax = a0
   const double dmax = first ? a0 : a1, dmin = first ? a1 : a0;
   const double q = sg * (dmin / dmax);
   const double r0 = first ? sg : q, r1 = first ? q : sg;
-  return dmin / (w1 * r0 + w2 * r1);
+  const double d = dmin / (w1 * r0 + w2 * r1);
+  return same ? d : 0.0;
 }
 
 // One value in each of R consecutive intervals i0 .. i0+R-1 of one sample row, at local coordinates sv[c]:
@@ -86,14 +89,13 @@ __device__ static inline double pchip_interior2(double del0, double del1, double
 // the spacing use the reciprocal table IH (round-off level difference to pchip_eval's true divisions).  mid[c]
 // is valid for i0 + c < n - 1.
 constexpr int kPchipRun = 8;
+// from a register window w[j] = v(i0 - 2 + j), j = 0 .. R+3 (entries outside the table are never used by a valid
+// result; for R = 1 entry 0 is not used at all)
 template <int R>
-__device__ static inline void pchip_run(const PchipTab& T, const double* V, size_t ldB, int i0, const double (&sv)[R],
-                                        double (&mid)[R]) {
+__device__ static inline void pchip_run_w(const PchipTab& T, const double (&w)[R + 4], int i0, const double (&sv)[R],
+                                          double (&mid)[R]) {
   const int n = T.n;
   auto clampi = [&](int k, int hi) OCS_INLINE { return k < 0 ? 0 : (k > hi ? hi : k); };
-  double w[R + 4];  // w[j] = v(i0 - 2 + j); clamped entries are never used by a valid result
-#pragma unroll
-  for (int j = 0; j < R + 4; ++j) w[j] = V[(size_t)clampi(i0 - 2 + j, n - 1) * ldB];
   double sec[R + 3];  // sec[j] = secant of interval i0 - 2 + j
 #pragma unroll
   for (int j = 0; j < R + 3; ++j) sec[j] = (w[j + 1] - w[j]) * T.IH[clampi(i0 - 2 + j, n - 2)];
@@ -126,6 +128,19 @@ __device__ static inline void pchip_run(const PchipTab& T, const double* V, size
     }
     mid[c] = m;
   }
+}
+template <int R>
+__device__ static inline void pchip_run(const PchipTab& T, const double* V, size_t ldB, int i0, const double (&sv)[R],
+                                        double (&mid)[R]) {
+  const int n = T.n;
+  double w[R + 4];
+#pragma unroll
+  for (int j = 0; j < R + 4; ++j) {
+    int k = i0 - 2 + j;
+    k = k < 0 ? 0 : (k > n - 1 ? n - 1 : k);
+    w[j] = V[(size_t)k * ldB];
+  }
+  pchip_run_w<R>(T, w, i0, sv, mid);
 }
 
 template <int R>
@@ -339,6 +354,13 @@ struct ControlGridArgs {
   double* u;           // the control grid, updated in place
   const int* status;   // only instances that are still active (status 0) take the new control (fb_sweep.m:85);
                        // a converged instance keeps its old one for the final sweep (:82)
+  // Error points == grid nodes: the weighted change |uNew - u| / (relTol |u| + absTol) at the nodes (fb_sweep.m:107)
+  // is folded in here, against the node samples of u that are being replaced, as one partial maximum per run of
+  // intervals: metric [runs][B] (-1: no valid value), reduced by k_fbs_advance.  The update then happens BEFORE the
+  // convergence decision: an instance that turns out converged has taken uNew, which is harmless because from
+  // then on it is frozen (its x, lam, J are the ones already computed from the old control, fb_sweep.m:82).
+  double* metric;
+  double relTol, absTol;
 };
 
 template <class P>
@@ -359,13 +381,26 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   double lmid[NS][R];
 #pragma unroll
   for (int k = 0; k < NS; ++k) pchip_mid_run<R>(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i0, a.TM, lmid[k]);
+  double wmax = 0.0;
+  bool any = false;
   auto emit = [&](int j, const double* x, const double* lam) OCS_INLINE {  // grid point j
     double tu[NTU], u[NC];
 #pragma unroll
     for (int k = 0; k < NTU; ++k) tu[k] = a.TU[(size_t)j * NTU + k];
     P::control_char(tu, x, lam, p, lb, ub, u);
 #pragma unroll
-    for (int c = 0; c < NC; ++c) a.u[((size_t)j * NC + c) * B + b] = u[c];
+    for (int c = 0; c < NC; ++c) {
+      double* dst = a.u + ((size_t)j * NC + c) * B + b;
+      if (a.metric && !(j & 1)) {  // a node: max() skips NaN (:108)
+        const double o = *dst;
+        const double w = fabs(u[c] - o) / (a.relTol * fabs(o) + a.absTol);
+        if (w == w) {
+          wmax = any ? fmax(wmax, w) : w;
+          any = true;
+        }
+      }
+      *dst = u[c];
+    }
   };
 #pragma unroll
   for (int c = 0; c < R; ++c) {
@@ -395,6 +430,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
     }
     emit(2 * N, x, lam);
   }
+  if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? wmax : -1.0;
 }
 
 // ---------------------------------------------------------------------------------------

@@ -61,10 +61,12 @@ template <class P>
 static void run_control_grid(const ControlGridArgs& a, hipStream_t s) {
   k_control_grid<P><<<dim3((a.batch + 255) / 256, (a.N + kPchipRun - 1) / kPchipRun), dim3(256), 0, s>>>(a);
 }
+int control_grid_parts(int N) { return (N + kPchipRun - 1) / kPchipRun; }
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
-                        const double* xmid, const double* lam, double* u, const int* status, hipStream_t s) {
+                        const double* xmid, const double* lam, double* u, const int* status, double* metric,
+                        double relTol, double absTol, hipStream_t s) {
   const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, make_tab(t), t.TM, u,
-                          status};
+                          status, metric, relTol, absTol};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, (g.N + kPchipRun - 1) / kPchipRun), dim3(256), args, s);

@@ -123,8 +123,12 @@ struct FbsTables {   // pchip node tables of an integrator grid, device pointers
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s);
+// metric (optional): [control_grid_parts(N)][B] partial maxima of the weighted change at the grid nodes (error points
+// == nodes), for launch_fbs_advance
+int control_grid_parts(int N);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
-                        const double* xmid, const double* lam, double* u, const int* status, hipStream_t s);
+                        const double* xmid, const double* lam, double* u, const int* status, double* metric,
+                        double relTol, double absTol, hipStream_t s);
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
                        const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,

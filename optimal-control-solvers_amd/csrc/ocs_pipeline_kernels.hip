@@ -127,7 +127,7 @@ struct FwdArgsPL {
 //   C processes block k-1   (inputs: slot (k-1) % NSLOT;    reads stage buffer (k-1) & 1).
 // The slot M overwrites in interval k last served block k+Q-NSLOT = k-2, read by C in interval k-1.
 // ---------------------------------------------------------------------------------------
-template <class P, bool OUT_X>
+template <class P, bool OUT_X, bool FRZ>
 __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
   constexpr int G = P::NS, NAUG = P::NAUG;
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
@@ -187,8 +187,9 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
     }, r);
     // a frozen trajectory writes every value to one scratch double (pointer stride 0): no branch around stores
-    const bool fz = a.frozen && a.frozen[b] != 0;
-    const size_t colB = fz ? 0 : (size_t)NAUG * B;
+    // (FRZ is a template parameter: without frozen lanes the column stride stays a scalar)
+    const bool fz = FRZ && a.frozen[b] != 0;
+    const size_t colB = (FRZ && fz) ? 0 : (size_t)NAUG * B;
     const double u0 = a.u[b];
     if (wave == 1) {
       // ---------------- S: state recursion ----------------
@@ -612,10 +613,16 @@ template <class P>
 static void run_forward_pl(const FwdArgsPL& a, hipStream_t s) {
   constexpr int TPW = 64 / P::NS;
   const dim3 grid(a.batch / TPW), block(192);
-  if (a.x)
-    k_forward_pl<P, true><<<grid, block, 0, s>>>(a);
-  else
-    k_forward_pl<P, false><<<grid, block, 0, s>>>(a);
+  if (a.frozen) {
+    if (a.x)
+      k_forward_pl<P, true, true><<<grid, block, 0, s>>>(a);
+    else
+      k_forward_pl<P, false, true><<<grid, block, 0, s>>>(a);
+  } else if (a.x) {
+    k_forward_pl<P, true, false><<<grid, block, 0, s>>>(a);
+  } else {
+    k_forward_pl<P, false, false><<<grid, block, 0, s>>>(a);
+  }
 }
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, const int* frozen, double* dump, hipStream_t s) {

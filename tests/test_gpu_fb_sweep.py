@@ -128,3 +128,36 @@ def test_fb_sweep_full_size_properties(ocs, oracle):
     for b in (0, 4095):
         ref = oracle.fb_sweep(oracle.TestOCProblem({"c": cs[b], "m": P["m"], "r": P["r"]}, BOUNDS), x0[:, b], tspan)
         assert sw[b] == ref["_sweeps"] and abs(r["J"][b].item() - ref["J"]) < RTOL * abs(ref["J"])
+
+
+@pytest.mark.parametrize("nS,N,batch", [(1, 400, 70), (1, 37, 5), (2, 203, 130), (4, 64, 64), (3, 9, 3), (1, 8, 64),
+                                        (1, 5, 2)])
+def test_fused_costate_update_equals_separate_kernels(ocs, oracle, nS, N, batch):
+    """With the error points on the grid nodes the costate pass, the in-place control update and the weighted
+    change (fb_sweep.m:95-96, :107) run as one kernel (update waves trailing the marching wave through an LDS ring of
+    lam nodes).  It must reproduce the separate kernels: same sweep counts, same maxChange history, same solution;
+    and the oracle instance by instance."""
+    rng = np.random.default_rng(N * 10 + nS)
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    T = 10.0 if N >= 200 else 1.0
+    tspan = oracle.linspace(0, T, N + 1)
+    x0 = rng.uniform(0.8, 2.0, (nS, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    base = {"nERROR_PTS": N + 1, "nINTERP_PTS": 33, "nSWEEPS": 40}
+    ra = ocs.fb_sweep_batch(prob, x0, tspan, dict(base))
+    rb = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=1))
+    assert np.array_equal(ra["sweeps"], rb["sweeps"]) and ra["sweeps"].min() > 0
+    # near convergence the weighted change is |du| ~ 1e-8 over 1e-7: one ulp in u (the reciprocal in the fused
+    # ControlChar) moves it by ~1e-9 relative
+    assert relerr(np.nan_to_num(ra["maxChange"]), np.nan_to_num(rb["maxChange"])) < 1e-6
+    assert np.array_equal(np.isnan(ra["maxChange"]), np.isnan(rb["maxChange"]))
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rb[key]) < 1e-12, key
+    for b in sorted({0, batch // 2, batch - 1}):
+        ref = oracle.fb_sweep(oracle.LogisticProblem(m, cs[b], P["r"], BOUNDS), x0[:, b], tspan, base)
+        assert ra["sweeps"][b] == ref["_sweeps"]
+        assert abs(ra["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
+        assert relerr(ra["x"][:, :, b], ref["x"]) < RTOL and relerr(ra["lam"][:, :, b], ref["lam"]) < RTOL
+        assert relerr(ra["u"][:, :, b], ref["u"]) < RTOL
