@@ -1,5 +1,7 @@
 """CPU tests of the product's host-side logic (no GPU compute): basis matrices, initial v,
 NLP bounds, uFunc and vectorInterpolant sampling of libocs against the CPU oracle."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -79,3 +81,31 @@ def test_user_problem_sources_compile_for_gfx950(ocs):
     with pytest.raises(ocs.OcsError) as e:
         ocs.UserProblem.check_source("__device__ void ocs_F(double t) { syntax error }", 1, 1, 0)
     assert e.value.code == -1 and "error" in str(e.value)
+
+
+def test_registry_and_option_validation_without_gpu(ocs):
+    """Handle creation and argument checks of the C-ABI that need no device: the LQ registry entry (BASELINE config 5),
+    the fusion switch of the control bases, MATLAB's linspace formula, the forward-backward-sweep option block."""
+    rng = np.random.default_rng(0)
+    A, Bu = rng.normal(size=(7, 7)), rng.normal(size=(7, 3))
+    p = ocs.LQProblem(A, Bu, np.ones(7), np.ones(3), 0.05, [[-1, 1]] * 3)
+    assert (p.nS, p.nC, p.nAug) == (7, 3, 8)
+    for nS, nC in ((33, 2), (4, 5)):          # no kernel instantiated: refused at creation, not at launch
+        with pytest.raises(ocs.OcsError) as e:
+            ocs.LQProblem(rng.normal(size=(nS, nS)), rng.normal(size=(nS, nC)), np.ones(nS), np.ones(nC), 0.05,
+                          [[-1, 1]] * nC)
+        assert e.value.code == -6
+    from ocs_amd import _lib
+    import oracle.oracle as orc0
+    t = _grid(orc0, 40, 4.0)
+    c = ocs.ChebyshevControl(t, 6, 1)
+    for mode in ("auto", "off", "on"):
+        assert c.set_fusion(mode) is c
+    assert _lib.lib.ocs_control_set_fusion(c._h, 7) == -1      # OCS_ERR_INVALID
+    # MATLAB linspace: end points pinned, (k*(b-a))/(n-1) rounding (differs from numpy's start + k*step)
+    import oracle.oracle as orc
+    for a, b, n in ((0.0, 10.0, 1001), (0.3, 7.7, 17), (5.0, 5.0, 3), (-2.0, 1.0, 2), (1.0, 2.0, 1)):
+        assert np.array_equal(ocs.linspace(a, b, n), orc.linspace(a, b, n))
+    o = _lib.FbsOptions()
+    assert _lib.lib.ocs_fbs_default_options(C.byref(o)) == 0
+    assert (o.uRelTol, o.uAbsTol, o.nSWEEPS, o.nERROR_PTS, o.nINTERP_PTS, o.fused_update_off) == (1e-7, 1e-7, 50, 1001, 1001, 0)
