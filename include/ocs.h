@@ -191,6 +191,9 @@ typedef struct ocs_fbs_options {
   int nINTERP_PTS; /* :22 */
   int fused_update_off; /* build option, default 0: with the error points on the grid nodes the costate pass, the control
                            update and the convergence metric run as one kernel; 1 keeps them separate (same results) */
+  int nWINDOWS;         /* build option, default 0 = automatic (currently 1): with the fused update the batch can be cut
+                           into this many windows that run their sweep loops on separate streams (marching kernels of
+                           one window under the streaming kernels of another); results do not depend on it */
 } ocs_fbs_options;
 int ocs_fbs_default_options(ocs_fbs_options *o);
 /* [x, lam(, J)] = compute_x_lam(_J)(prob, x0, tspan, u, RelTol, AbsTol)   compute_x_lam.m:1-19, compute_x_lam_J.m:1-21

@@ -17,6 +17,13 @@ struct ocs_fbs_state {
   DevBuf KE, SE, TE, TUE, KI, SI, TI, TUI;
   unsigned long long tu_version = 0;
   const ocs_problem_s* tu_prob = nullptr;
+  // windows of the batch on their own streams (fb_sweep with the fused control update)
+  std::vector<hipStream_t> wstreams;
+  std::vector<hipEvent_t> wevents;  // two per window: "sweep done" (ping-pong)
+  hipEvent_t fork = nullptr, stag = nullptr;
+  int* h_nact = nullptr;            // pinned: [windows][nSWEEPS] instances still active after each sweep
+  int h_nact_cap = 0;
+  DevBuf nact_slots;                // device: the same counters
   // work arrays
   DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid, dump;
 };
@@ -27,6 +34,12 @@ void ocs_fbs_state_free(ocs_fbs_state* s) {
                     &s->TI, &s->TUI, &s->xaug, &s->xmid, &s->lam, &s->lmid, &s->ugrid, &s->uerr, &s->uint_, &s->J,
                     &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage, &s->metric, &s->anyvalid, &s->dump};
   for (DevBuf* b : bufs) b->release();
+  s->nact_slots.release();
+  for (hipStream_t st : s->wstreams) (void)hipStreamDestroy(st);
+  for (hipEvent_t e : s->wevents) (void)hipEventDestroy(e);
+  if (s->fork) (void)hipEventDestroy(s->fork);
+  if (s->stag) (void)hipEventDestroy(s->stag);
+  if (s->h_nact) (void)hipHostFree(s->h_nact);
   delete s;
 }
 
@@ -126,6 +139,7 @@ int ocs_fbs_default_options(ocs_fbs_options* o) {
   o->nERROR_PTS = 1001;   // :21
   o->nINTERP_PTS = 1001;  // :22
   o->fused_update_off = 0;
+  o->nWINDOWS = 0;
   return OCS_OK;
 }
 
@@ -232,7 +246,93 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const FbsTables tb = tabs(g);
   const int* usel = (const int*)f->usel.p;  // selects the old / new buffer of the ERROR-POINT samples only
   int nactive = batch;
-  for (int sweep = 1; sweep <= opt->nSWEEPS && nactive > 0; ++sweep) {  // :79
+  // ---- fused update, several windows of the batch on their own streams -----------------------------------------
+  // The two marching kernels of a sweep (forward, costate) are latency-bound and leave most of the GPU idle; the
+  // streaming kernels (pchip, control update) are HBM-bound.  Independent windows of the batch, each running its own
+  // sweep loop on its own stream and started one forward pass apart, let one window's marching kernels run under
+  // another's streaming kernels.  Each window stops on its own count of active instances.
+  int nwin = 1;
+  if (fusedup) {
+    // Automatic = 1 for now: measured at batch 16384, 4 windows are host-bound (8 runtime calls per window and sweep,
+    // ~190 us, against ~290 us of GPU time per round) and slower than one stream; a captured graph per window is
+    // the missing piece.  At batch 65536 windows neither gain nor lose (the streaming kernels dominate).
+    nwin = opt->nWINDOWS > 0 ? opt->nWINDOWS : 1;
+    while (nwin > 1 && (batch + nwin - 1) / nwin < 64) --nwin;
+  }
+  if (fusedup && nwin > 1) {
+    const int W = (((batch + nwin - 1) / nwin + 63) / 64) * 64;  // whole tiles of the pipeline kernels
+    nwin = (batch + W - 1) / W;
+    const int nsw = opt->nSWEEPS;
+    while ((int)f->wstreams.size() < nwin) {
+      hipStream_t st;
+      HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+      f->wstreams.push_back(st);
+      for (int e = 0; e < 2; ++e) {
+        hipEvent_t ev;
+        HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        f->wevents.push_back(ev);
+      }
+    }
+    if (!f->fork) HIP_TRY(hipEventCreateWithFlags(&f->fork, hipEventDisableTiming));
+    if (!f->stag) HIP_TRY(hipEventCreateWithFlags(&f->stag, hipEventDisableTiming));
+    if (f->h_nact_cap < nwin * nsw) {
+      if (f->h_nact) (void)hipHostFree(f->h_nact);
+      f->h_nact = nullptr;
+      HIP_TRY(hipHostMalloc((void**)&f->h_nact, sizeof(int) * (size_t)nwin * nsw));
+      f->h_nact_cap = nwin * nsw;
+    }
+    OCS_TRY(f->nact_slots.ensure(sizeof(int) * (size_t)nwin * nsw));
+    HIP_TRY(hipMemsetAsync(f->nact_slots.p, 0, sizeof(int) * (size_t)nwin * nsw, s));
+    HIP_TRY(hipEventRecord(f->fork, s));
+    std::vector<int> done(nwin, 0), last(nwin, 0), act(nwin, 0);  // done: finished; last: sweeps enqueued
+    int* dslots = (int*)f->nact_slots.p;
+    auto enqueue = [&](int j, int sweep) -> int {
+      const int off = j * W, cnt = std::min(W, batch - off);
+      hipStream_t st = f->wstreams[j];
+      ProblemDesc pj = pd;
+      if (pj.pb) pj.pb += off;
+      FwdOpts fo;
+      fo.frozen = status + off;
+      fo.dump = f->dump.d() + off;
+      fo.ld = batch;
+      LAUNCH_TRY(launch_forward(pj, gd, cnt, x0 + off, f->ugrid.d() + off, xaug + off, J + off, fo, st));
+      if (sweep == 1 && j + 1 < nwin) HIP_TRY(hipEventRecord(f->stag, st));  // the next window starts one pass later
+      LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, cnt, xaug + off, f->xmid.d() + off, st, batch));
+      LAUNCH_TRY(launch_costate(pj, gd, cnt, xaug + off, nAug, f->xmid.d() + off, f->ugrid.d() + off, status + off,
+                                f->dump.d() + off, lam + off, st, batch));
+      LAUNCH_TRY(launch_control_grid(pj, gd, tb, cnt, xaug + off, nAug, f->xmid.d() + off, lam + off, f->ugrid.d() + off,
+                                     status + off, f->metric.d() + off, opt->uRelTol, opt->uAbsTol, st, batch));
+      int* slot = dslots + (size_t)j * nsw + (sweep - 1);
+      LAUNCH_TRY(launch_fbs_advance(cnt, sweep, nparts, f->metric.d() + off, (int*)f->anyvalid.p + off,
+                                    (int*)f->usel.p + off, status + off, mc + off, slot, st, batch));
+      HIP_TRY(hipMemcpyAsync(f->h_nact + (size_t)j * nsw + (sweep - 1), slot, sizeof(int), hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipEventRecord(f->wevents[2 * j + (sweep & 1)], st));
+      return OCS_OK;
+    };
+    for (int j = 0; j < nwin; ++j) {  // sweep 1, staggered
+      HIP_TRY(hipStreamWaitEvent(f->wstreams[j], f->fork, 0));
+      if (j > 0) HIP_TRY(hipStreamWaitEvent(f->wstreams[j], f->stag, 0));
+      OCS_TRY(enqueue(j, 1));
+      last[j] = 1;
+    }
+    for (int live = nwin; live > 0;) {  // round robin: a window gets its next sweep when the previous one is back
+      for (int j = 0; j < nwin; ++j) {
+        if (done[j]) continue;
+        HIP_TRY(hipEventSynchronize(f->wevents[2 * j + (last[j] & 1)]));
+        act[j] = f->h_nact[(size_t)j * nsw + (last[j] - 1)];
+        if (act[j] == 0 || last[j] >= nsw) {
+          done[j] = 1;
+          --live;
+          continue;
+        }
+        ++last[j];
+        OCS_TRY(enqueue(j, last[j]));
+      }
+    }
+    nactive = 0;
+    for (int j = 0; j < nwin; ++j) nactive += act[j];
+  }
+  for (int sweep = 1; !(fusedup && nwin > 1) && sweep <= opt->nSWEEPS && nactive > 0; ++sweep) {  // :79
     // uNew = sweep(u): compute_x_lam (:95) ...
     // instances that converged in an earlier sweep are integrated along but store nothing: their x, lam, J stay
     // those of the sweep they converged in (final_sweep(u), :82)

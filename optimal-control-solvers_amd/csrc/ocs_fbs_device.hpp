@@ -159,11 +159,11 @@ __device__ static inline void pchip_mid_run(const PchipTab& T, const double* V, 
 // blockIdx.y = run of kPchipRun intervals
 __global__ __launch_bounds__(256) void k_pchip_mid(PchipTab T, int nrows, int ld, int batch,
                                                    const double* __restrict__ TM, const double* __restrict__ V,
-                                                   double* __restrict__ out) {
+                                                   double* __restrict__ out, int ldb) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int i0 = blockIdx.y * kPchipRun;
   if (b >= batch || i0 >= T.n - 1) return;
-  const size_t B = (size_t)batch;
+  const size_t B = (size_t)(ldb ? ldb : batch);  // row distance (a window of a larger batch) / trajectories here
   for (int r = 0; r < nrows; ++r) {
     double mid[kPchipRun];
     pchip_mid_run<kPchipRun>(T, V + (size_t)r * B + b, (size_t)ld * B, i0, TM, mid);
@@ -190,6 +190,7 @@ struct CostateArgs {
   const int* frozen;   // optional [B]: instances with frozen[b] != 0 (converged in an earlier sweep) store nothing
   double* dump;        // [B] scratch for their stores
   double* lam;         // [N+1][nS][B]
+  int ld;              // row distance when the launch covers a window of a larger batch; 0 = batch
 };
 
 template <class P, int PF>
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
   using Rec = StepRec<NTC>;
   const int b0 = blockIdx.x * 64 + threadIdx.x;
   const int b = b0 < a.batch ? b0 : a.batch - 1;
-  const size_t B = (size_t)a.batch;
+  const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int N = a.N;
   const uniform_ptr PS = as_uniform(a.ps);
   const typename P::Par p = P::load(ParamSrc{PS, a.pb, a.pmask, B, b});
@@ -361,6 +362,7 @@ struct ControlGridArgs {
   // then on it is frozen (its x, lam, J are the ones already computed from the old control, fb_sweep.m:82).
   double* metric;
   double relTol, absTol;
+  int ld;  // row distance when the launch covers a window of a larger batch; 0 = batch
 };
 
 template <class P>
@@ -369,7 +371,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int i0 = blockIdx.y * R;  // first interval of this thread's run
   if (b >= a.batch || a.status[b] != 0) return;
-  const size_t B = (size_t)a.batch;
+  const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int N = a.N;
   const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
   double lb[NC], ub[NC];
@@ -563,7 +565,8 @@ __global__ void k_tu_at(int nq, const double* __restrict__ tq, const double* __r
 // ---------------------------------------------------------------------------------------
 __global__ void k_fbs_advance(int batch, int sweep, int nparts, const double* __restrict__ metric,
                               int* __restrict__ anyvalid, int* __restrict__ usel, int* __restrict__ status,
-                              double* __restrict__ maxChange, int* __restrict__ nactive) {
+                              double* __restrict__ maxChange, int* __restrict__ nactive, int ldb) {
+  const size_t ld = (size_t)(ldb ? ldb : batch);  // row distance of metric / maxChange
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   bool still = false;
   if (b < batch) {
@@ -573,14 +576,14 @@ __global__ void k_fbs_advance(int batch, int sweep, int nparts, const double* __
     for (; q + 8 <= nparts; q += 8) {  // eight independent loads in flight
       double m[8];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) m[j] = metric[(size_t)(q + j) * batch + b];
+      for (int j = 0; j < 8; ++j) m[j] = metric[(size_t)(q + j) * ld + b];
 #pragma unroll
       for (int j = 0; j < 8; ++j) mx = fmax(mx, m[j]);
     }
-    for (; q < nparts; ++q) mx = fmax(mx, metric[(size_t)q * batch + b]);
+    for (; q < nparts; ++q) mx = fmax(mx, metric[(size_t)q * ld + b]);
     if (mx < 0.0) mx = __builtin_nan("");
     if (status[b] == 0) {
-      maxChange[(size_t)(sweep - 1) * batch + b] = mx;  // the value :109 prints
+      maxChange[(size_t)(sweep - 1) * ld + b] = mx;  // the value :109 prints
       if (mx <= 1.0) {                                   // :110
         status[b] = sweep;
       } else {

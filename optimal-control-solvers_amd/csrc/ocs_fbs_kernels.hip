@@ -34,9 +34,10 @@ static inline int hip_rc3(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 static PchipTab make_tab(const FbsTables& t) { return PchipTab{t.n, t.TN, t.HN, t.W1, t.W2, t.IH}; }
 
-int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s) {
-  k_pchip_mid<<<dim3((batch + 255) / 256, (t.n - 1 + kPchipRun - 1) / kPchipRun), dim3(256), 0, s>>>(make_tab(t), nrows, ld,
-                                                                                                    batch, t.TM, V, out);
+int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s,
+                     int ldb) {
+  k_pchip_mid<<<dim3((batch + 255) / 256, (t.n - 1 + kPchipRun - 1) / kPchipRun), dim3(256), 0, s>>>(
+      make_tab(t), nrows, ld, batch, t.TM, V, out, ldb);
   return hip_rc3(hipGetLastError());
 }
 
@@ -45,9 +46,9 @@ static void run_costate(const CostateArgs& a, hipStream_t s) {
   k_costate<P, 4><<<dim3((a.batch + 63) / 64), dim3(64), 0, s>>>(a);
 }
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
-                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s) {
+                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb) {
   if (frozen && !dump) return -1;
-  const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam};
+  const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam, ldb};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_COSTATE, dim3((batch + 63) / 64), dim3(64), args, s);
@@ -64,9 +65,9 @@ static void run_control_grid(const ControlGridArgs& a, hipStream_t s) {
 int control_grid_parts(int N) { return (N + kPchipRun - 1) / kPchipRun; }
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
-                        double relTol, double absTol, hipStream_t s) {
+                        double relTol, double absTol, hipStream_t s, int ldb) {
   const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, make_tab(t), t.TM, u,
-                          status, metric, relTol, absTol};
+                          status, metric, relTol, absTol, ldb};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, (g.N + kPchipRun - 1) / kPchipRun), dim3(256), args, s);
@@ -113,9 +114,9 @@ int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hi
 
 int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
-                       double* maxChange, int* nactive, hipStream_t s) {
+                       double* maxChange, int* nactive, hipStream_t s, int ldb) {
   k_fbs_advance<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, sweep, nparts, metric, anyvalid, usel, status,
-                                                                 maxChange, nactive);
+                                                                 maxChange, nactive, ldb);
   return hip_rc3(hipGetLastError());
 }
 

@@ -45,7 +45,7 @@ int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const
                        const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
                        hipStream_t s);
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                      double* x, double* J, const int* frozen, double* dump, hipStream_t s);
+                      double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s);
 bool rowsplit_supported(Functor f, int nS, int nC);
 int launch_forward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, hipStream_t s);
@@ -70,6 +70,8 @@ struct FwdOpts {
   const double* Jadd = nullptr; // J = Jadd + x(end,end)
   const int* frozen = nullptr;  // [B]: trajectories with frozen[b] != 0 store nothing (fb_sweep: converged instances)
   double* dump = nullptr;       // [B] scratch the stores of frozen trajectories go to
+  int ld = 0;                   // row distance of the batch-minor arrays when the call covers a window of a larger
+                                // batch (pointers offset by the caller, `batch` = size of the window); 0 = batch
 };
 struct BwdOpts {
   int mapping = MAP_AUTO;
@@ -120,15 +122,17 @@ struct FbsTables {   // pchip node tables of an integrator grid, device pointers
   const double* TM;  // [n-1] interval midpoints
   const double* IH;  // [n-1] reciprocal spacings
 };
-int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s);
+// ldb: row distance of V / out when the call covers a window of a larger batch (0 = batch)
+int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s,
+                     int ldb = 0);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
-                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s);
+                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb = 0);
 // metric (optional): [control_grid_parts(N)][B] partial maxima of the weighted change at the grid nodes (error points
 // == nodes), for launch_fbs_advance
 int control_grid_parts(int N);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
-                        double relTol, double absTol, hipStream_t s);
+                        double relTol, double absTol, hipStream_t s, int ldb = 0);
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
                        const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
@@ -136,7 +140,7 @@ int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const i
 int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
 int control_pts_parts(int nq);  // rows of the partial-maximum array `metric` [parts][B] that launch_control_pts fills
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
-                       double* maxChange, int* nactive, hipStream_t s);
+                       double* maxChange, int* nactive, hipStream_t s, int ldb = 0);
 
 // registry queries (host)
 bool functor_supported(Functor f, int nS, int nC);

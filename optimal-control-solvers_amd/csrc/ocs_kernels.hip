@@ -174,28 +174,30 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
   if (p.functor == Functor::LQ) return launch_forward_lq(p, g, batch, x0, u, x, J, o, s);
   const bool plain = !o.uconst && !o.Jadd;
   int map = choose_mapping(p, g.N, batch, o.mapping, plain, false, x != nullptr);
-  if (map == MAP_ROWSPLIT && o.frozen && o.mapping == MAP_AUTO) map = MAP_LANE;  // no frozen lanes in that kernel
+  if (map == MAP_ROWSPLIT && (o.frozen || o.ld) && o.mapping == MAP_AUTO) map = MAP_LANE;  // not in that kernel
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, false) : 0;
     if (N1 == 0 || (N1 < g.N && !x)) return -1;  // the split needs the boundary column in memory
     GridDesc g1 = g;
     g1.N = N1;
-    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, s);
+    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s);
     if (rc || N1 == g.N) return rc;
     // remaining steps N1 .. N-1 on the lane kernel, continuing from column N1 (state rows and running objective)
-    const size_t col = (size_t)(p.nS + 1) * batch, ucol = (size_t)p.nC * batch;
+    const size_t ldb = o.ld ? o.ld : batch;
+    const size_t col = (size_t)(p.nS + 1) * ldb, ucol = (size_t)p.nC * ldb;
     double* xb = x + (size_t)N1 * col;
     const FwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
-                    p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, o.frozen, o.dump, xb + (size_t)p.nS * batch};
+                    p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, o.frozen, o.dump, xb + (size_t)p.nS * ldb,
+                    o.ld};
     OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, false, s));
     return hip_rc(hipGetLastError());
   }
   if (map == MAP_ROWSPLIT) {
-    if (!plain || o.frozen || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;
+    if (!plain || o.frozen || o.ld || !rowsplit_supported(p.functor, p.nS, p.nC)) return -1;
     return launch_forward_rs(p, g, batch, x0, u, x, J, s);
   }
   if (o.uconst && !x) return -1;
-  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.frozen, o.dump, nullptr};
+  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.frozen, o.dump, nullptr, o.ld};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     const int kid = o.uconst ? UK_FWD_UCONST : (x ? UK_FWD_X : UK_FWD_J);

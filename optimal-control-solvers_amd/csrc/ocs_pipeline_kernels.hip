@@ -117,6 +117,7 @@ struct FwdArgsPL {
   long long* dbg;  // diagnostic build (-DOCS_PL_STAMPS) only: per-workgroup cycle sums; nullptr otherwise
   const int* frozen;  // optional [B]: trajectories with frozen[b] != 0 store nothing (as in FwdArgs)
   double* dump;       // [B] scratch for their stores
+  int ld;             // row distance of the arrays when the launch covers a window of a larger batch; 0 = batch
 };
 
 // ---------------------------------------------------------------------------------------
@@ -137,7 +138,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];  // [slot]{records | u}
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
-  const size_t B = (size_t)a.batch;
+  const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int nb = a.N / D;
   const int bw = blockIdx.x * TPW;  // first trajectory of this workgroup
 
@@ -625,9 +626,9 @@ static void run_forward_pl(const FwdArgsPL& a, hipStream_t s) {
   }
 }
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                      double* x, double* J, const int* frozen, double* dump, hipStream_t s) {
+                      double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s) {
   if (!pipeline_shape_ok(p.nS, g.N, batch, false) || (frozen && !dump)) return -1;
-  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump};
+  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump, ld};
 #ifdef OCS_PL_STAMPS
   static long long* dbg = nullptr;
   const int nwg = batch / (64 / p.nS);

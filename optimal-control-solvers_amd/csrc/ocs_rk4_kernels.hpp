@@ -64,6 +64,8 @@ struct FwdArgs {
   double* dump;         //   a converged instance keeps the x, J of the sweep it converged in); its stores go to dump[b]
   const double* yc0;    // optional [B]: running objective at the first node (a pass continued from another
                         //               kernel's last column; default 0, RK4Integrator.m:33)
+  int ld;               // distance between rows of the batch-minor arrays when it is not `batch` (a launch on a
+                        // window of a larger batch: pointers are offset, `batch` counts the window); 0 = batch
 };
 
 // Lanes past the end of the batch are clamped onto the last trajectory: they recompute it and
@@ -75,7 +77,7 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
   using Rec = StepRec<NTC>;
   const int b0 = blockIdx.x * 64 + threadIdx.x;
   const int b = b0 < a.batch ? b0 : a.batch - 1;
-  const size_t B = (size_t)a.batch;
+  const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int N = a.N;
   const uniform_ptr PS = as_uniform(a.ps);
   const double* REC = a.REC;

@@ -10,7 +10,7 @@ cs = rng.uniform(1.0, 2.0, batch)
 prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
 prob.set_batch_params([0], cs[None, :])
 integ = ocs.RK4Integrator(ocs.linspace(0, 10, 1001))
-opts = {"fused_update_off": int(os.environ.get("OFF", 0))}
+opts = {"fused_update_off": int(os.environ.get("OFF", 0)), "nWINDOWS": int(os.environ.get("NWIN", 0))}
 r = ocs.fb_sweep_dev(prob, integ, x0, opts); torch.cuda.synchronize()
 t0 = time.perf_counter()
 for _ in range(3): r = ocs.fb_sweep_dev(prob, integ, x0, opts)
