@@ -244,12 +244,19 @@ def main():
 
     for _ in range(args.warmup):
         one_step()
+    torch.cuda.synchronize()
+    # per-kernel durations (roofline): K untimed steps with HIP events between the two kernels
+    for k in range(args.steps):
+        one_step(k)
+    torch.cuda.synchronize()
+    # (HIP event records between the kernels cost a few us of GPU idle time each, so the timed steps below carry none;
+    #  replaying the two kernels from a captured graph was measured slower than plain stream launches: 222 vs 209 us)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step(k)
+        one_step()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -297,7 +304,7 @@ def main():
                        "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}",
                        "mapping": "automatic (batch <= 8192: wave-specialised pipeline, one state row per lane)"},
             "roofline": {"bound": "hbm", "kernel": "k_backward_pl (compute_adjoints + compute_dJdu; at this batch the "
-                                                   "wave-specialised kernel, plus its 3 us cost-row fill)",
+                                                   "wave-specialised kernel)",
                          "achieved": bytes_bwd / t_bwd / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": bytes_bwd / t_bwd / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
                          "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_s": t_bwd},

@@ -336,7 +336,7 @@ struct BwdArgsPL {
   const double* xck;
   const double* u;
   const double* lamT;
-  double* lam;   // state rows only; the constant cost row is written by k_fill_lam_cost_row
+  double* lam;   // state rows by the adjoint wave A, the constant cost row by R
   double* dJdu;
   double* lam0;
   long long* dbg;  // diagnostic build only
@@ -402,13 +402,24 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   const size_t colB = (size_t)NAUG * B;
 
   if (wave == 1) {
-    // ---------------- R: stage states and the affine coefficients of the adjoint rows ----------------
+    // ---------------- R: stage states; also the constant cost row of lam ----------------
+    // R is the compute wave with slack (151 of 252 cycles per step): it writes lam(end, :) = lamT(end) for the
+    // columns of its block, D / (64 / TPW) stores per lane and block (a separate fill kernel used to: 8 us + a launch)
+    const int tl2 = lane % TPW, so = lane / TPW;  // this lane's trajectory and first step offset for those stores
+    const double lamc2 = a.lamT ? a.lamT[(size_t)G * B + bw + tl2] : 1.0;
+    double* lc = a.lam + (size_t)G * B + bw + tl2;
+    if (OUT_LAM && so == 0) lc[(size_t)N * colB] = lamc2;
     long long tb = 0, tc = 0;
     for (int k = 0; k <= nb + 1; ++k) {
       const long long t0 = PL_T();
       lds_barrier();
       const long long t1 = PL_T();
       tb += t1 - t0;
+      if (OUT_LAM && k < nb) {
+        const int itop = N - 1 - k * D;
+#pragma unroll
+        for (int s2 = 0; s2 < D; s2 += 64 / TPW) lc[(size_t)(itop - s2 - so) * colB] = lamc2;
+      }
       if (k < nb) {
         const double* slot = &inp[k % NSLOT][0];
         const double* us = slot + UOFF + tl;
@@ -588,15 +599,6 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   }
 }
 
-// lam(end, :) is constant along a trajectory (the last row of dFdx_times_vec is zero): one streaming fill
-__global__ void k_fill_lam_cost_row(int N, int nAug, int batch, const double* __restrict__ lamT,
-                                    double* __restrict__ lam) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  const int i = blockIdx.y;
-  if (b >= batch || i > N) return;
-  const double v = lamT ? lamT[(size_t)(nAug - 1) * batch + b] : 1.0;
-  lam[((size_t)i * nAug + (nAug - 1)) * batch + b] = v;
-}
 
 // ---------------------------------------------------------------------------------------
 bool pipeline_supported(Functor f, int nS, int nC) {
@@ -685,8 +687,6 @@ int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const
   (void)hipMemsetAsync(dbgb, 0, sizeof(long long) * 16 * nwg, s);
   a.dbg = dbgb;
 #endif
-  if (lam)
-    k_fill_lam_cost_row<<<dim3((batch + 255) / 256, g.N + 1), dim3(256), 0, s>>>(g.N, p.nS + 1, batch, lamT, lam);
   if (p.nS == 2)
     run_backward_pl<LogisticK<2>>(a, s);
   else if (p.nS == 4)
