@@ -13,7 +13,9 @@ struct ocs_control_s {
   std::vector<double> t, pts, B;  // B: nBasis x nT column-major (property B)
   double t0 = 0, t1 = 0;
   // device copies: CSC (for u = v*B) and CSR (for dJdv = dJdu*B')
-  DevBuf d_colptr, d_row, d_cval, d_rowptr, d_col, d_rval, d_BT, d_BT16;
+  DevBuf d_colptr, d_row, d_cval, d_rowptr, d_col, d_rval, d_BT, d_BT16, d_CT;
+  bool banded = false;  // every column has at most two consecutive non-zeros and the band moves up by at most one row
+  int band_r0 = 0;      // per column (PWLinear, PWConstant): column table d_CT for the fused banded kernels
   int fuse_mode = 0;  // ocs_control_set_fusion: 0 automatic, 1 never, 2 whenever the fused kernels support the case
   bool dense = false;  // more than half of B is non-zero and nBasis <= 32: register-resident dense kernels
   bool uploaded = false;
@@ -153,6 +155,52 @@ static int upload_control(ocs_control_s* c) {
     OCS_TRY(c->d_BT16.ensure(sizeof(double) * BT16.size()));
     HIP_TRY(hipMemcpy(c->d_BT16.p, BT16.data(), sizeof(double) * BT16.size(), hipMemcpyHostToDevice));
   }
+  {  // column table of a banded basis: {w0, w1, adv, pad} with B(:,j) = w0 e_r + w1 e_{r+1}, r_j = r_{j-1} + adv
+    const int R = fused_banded_rec();
+    std::vector<double> ct((size_t)nT * R, 0.0);
+    bool ok = nB >= 1;
+    int rprev = 0;
+    for (int j = 0; ok && j < nT; ++j) {
+      int first = -1, last = -1, cnt = 0;
+      for (int i = 0; i < nB; ++i)
+        if (c->B[i + (size_t)nB * j] != 0.0) {
+          if (first < 0) first = i;
+          last = i;
+          ++cnt;
+        }
+      if (cnt == 0 || cnt > 2 || last - first + 1 != cnt) {
+        ok = false;
+        break;
+      }
+      int r;
+      if (cnt == 2) {
+        r = first;
+      } else if (j == 0) {
+        r = first;
+      } else if (first == rprev || first == rprev + 1) {
+        r = rprev;          // the single entry sits inside the band of the column before
+      } else {
+        r = first - 1;      // ... or on the upper row of a band one row up
+      }
+      if (j > 0 && (r - rprev < 0 || r - rprev > 1)) {
+        ok = false;
+        break;
+      }
+      double* e = &ct[(size_t)j * R];
+      e[0] = (r >= 0 && r < nB) ? c->B[r + (size_t)nB * j] : 0.0;
+      e[1] = (r + 1 < nB) ? c->B[(r + 1) + (size_t)nB * j] : 0.0;
+      e[2] = j == 0 ? 0.0 : (double)(r - rprev);
+      e[3] = 0.0;
+      if (j == 0) c->band_r0 = r;
+      rprev = r;
+    }
+    c->banded = ok && !c->dense;
+    if (c->banded) {
+      ct[(size_t)(nT - 1) * R + 3] = (double)rprev;  // first row of the last column (start of the adjoint's cursors)
+      OCS_TRY(c->d_CT.ensure(sizeof(double) * ct.size()));
+      HIP_TRY(hipMemcpy(c->d_CT.p, ct.data(), sizeof(double) * ct.size(), hipMemcpyHostToDevice));
+    }
+  }
   if (!c->stream) HIP_TRY(hipStreamCreate(&c->stream));
   c->uploaded = true;
   return OCS_OK;
@@ -230,7 +278,7 @@ int ocs_control_create(ocs_control* out, int kind, const double* t, int nt, int 
 int ocs_control_destroy(ocs_control c) {
   if (!c) return OCS_OK;
   if (c->stream) (void)hipStreamDestroy(c->stream);
-  DevBuf* bufs[] = {&c->d_colptr, &c->d_row, &c->d_cval, &c->d_rowptr, &c->d_col, &c->d_rval, &c->d_BT, &c->d_BT16, &c->d_v,
+  DevBuf* bufs[] = {&c->d_colptr, &c->d_row, &c->d_cval, &c->d_rowptr, &c->d_col, &c->d_rval, &c->d_BT, &c->d_BT16, &c->d_CT, &c->d_v,
                     &c->d_u, &c->d_dJdu, &c->d_dJdv, &c->d_stage, &c->d_x0, &c->d_J, &c->d_idx};
   for (DevBuf* b : bufs) b->release();
   delete c;
@@ -422,7 +470,14 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   // 262144 6.28 / 2.02.  With 3-4 states and a small batch the wave-specialised unfused passes are kept.
   const bool fusable = c->dense && g->kind == 0 && fused_control_supported(p->functor, p->nS, p->nC, c->nBasis);
   const bool fused = fusable && c->fuse_mode != 1 && (c->fuse_mode == 2 || p->nS <= 2 || batch >= 8192);
-  if (!fused) {
+  // Banded basis (PWLinear, PWConstant): the same with two live coefficient rows per trajectory
+  // (ocs_fused_banded_kernels.hip)
+  // Measured (TestOCProblem, N = 500, PWLinear 101 points; ms per evaluation unfused / fused): batch 4096 0.16 / 0.31,
+  // 65536 0.86 / 0.46 -- at small batch the unfused path has the wave-specialised forward kernel and time-parallel
+  // sparse basis kernels, at large batch the traffic of u and dJdu decides.
+  const bool fusedb = !fused && c->banded && g->kind == 0 && fused_banded_supported(p->functor, p->nS, p->nC) &&
+                      c->fuse_mode != 1 && (c->fuse_mode == 2 || batch >= 32768);
+  if (!fused && !fusedb) {
     OCS_TRY(c->d_u.ensure(sizeof(double) * (size_t)nU * B));
     OCS_TRY(c->d_dJdu.ensure(sizeof(double) * (size_t)nU * B));
     OCS_TRY(ocs_control_compute_u_dev(c, batch, v, c->d_u.d(), stream));                     // :139 / :145
@@ -442,6 +497,19 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   double* lam0 = nullptr;
   if (nFree > 0)
     lam0 = reinterpret_cast<double*>(static_cast<char*>(c->d_idx.p) + ((sizeof(int) * nFree + 7) / 8) * 8);
+  if (fusedb) {
+    OCS_TRY(bind_problem(g, p, batch, s));
+    OCS_TRY(g->d_ck.ensure(sizeof(double) * (size_t)nAug * (g->N + 1) * B));
+    g->ck = nullptr;
+    HIP_TRY(hipMemsetAsync(dJdv, 0, sizeof(double) * (size_t)nV * B, s));  // rows outside every band
+    LAUNCH_TRY(launch_forward_fb(describe(p), describe(g), batch, c->nBasis, c->band_r0, c->d_CT.d(), v, x0, g->d_ck.d(),
+                                 J, s));
+    LAUNCH_TRY(launch_backward_fb(describe(p), describe(g), batch, c->nBasis, c->band_r0, c->d_CT.d(), v, g->d_ck.d(),
+                                  dJdv, lam0, s));
+    if (nFree > 0)
+      LAUNCH_TRY(launch_gather_rows(nFree, batch, (const int*)c->d_idx.p, lam0, dJdv + (size_t)nV * B, s));
+    return OCS_OK;
+  }
   if (fused) {
     OCS_TRY(bind_problem(g, p, batch, s));
     OCS_TRY(g->d_ck.ensure(sizeof(double) * (size_t)nAug * (g->N + 1) * B));

@@ -112,6 +112,15 @@ int launch_forward_fc(const ProblemDesc& p, const GridDesc& g, int batch, int nB
 int launch_backward_fc(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, const double* BT16,
                        const double* v, const double* ck, double* dJdv, double* lam0, hipStream_t s);
 
+// the same for a banded basis (PWLinear, PWConstant; ocs_fused_banded_kernels.hip).  CT: column table
+// [2N+1][fused_banded_rec()] = {w0, w1, adv, pad}, r0 the first row of column 0; dJdv must be zero-filled
+bool fused_banded_supported(Functor f, int nS, int nC);
+int fused_banded_rec();
+int launch_forward_fb(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, int r0, const double* CT,
+                      const double* v, const double* x0, double* ck, double* J, hipStream_t s);
+int launch_backward_fb(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, int r0, const double* CT,
+                       const double* v, const double* ck, double* dJdv, double* lam0, hipStream_t s);
+
 // forward-backward sweep (ocs_fbs_kernels.hip)
 struct FbsTables {   // pchip node tables of an integrator grid, device pointers
   int n;             // number of nodes N+1

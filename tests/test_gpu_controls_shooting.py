@@ -268,3 +268,39 @@ def test_fused_control_objective_gradient(ocs, oracle, nS, nB, N, batch):
     with pytest.raises(Exception):
         g.compute_adjoints(pg, np.zeros((1, 2 * N + 1, batch)))
     cg.set_fusion("auto")
+
+
+@pytest.mark.parametrize("kind,nS,nB,N,batch", [("lin", 1, 101, 500, 70), ("lin", 1, 2, 7, 3), ("lin", 2, 11, 50, 130),
+                                                ("lin", 4, 33, 64, 64), ("lin", 1, 51, 50, 5), ("lin", 3, 300, 40, 9),
+                                                ("const", 1, 50, 500, 70), ("const", 2, 1, 9, 65), ("const", 4, 7, 50, 33),
+                                                ("const", 1, 100, 50, 4), ("lin", 1, 6, 1, 2)])
+def test_fused_banded_control_objective_gradient(ocs, oracle, kind, nS, nB, N, batch):
+    """single_shooting.m:137-150 with the reference's default bases (PWLinearControl.m:31-62, PWConstantControl.m:30-50)
+    applied inside the RK4 kernels: two live coefficient rows per trajectory, u and dJdu never in memory.  Against
+    the oracle's unfused composition and this library's unfused path, including a non-uniform grid, more control
+    points than grid samples (falls back to the unfused kernels), free initial states, a per-trajectory parameter."""
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    T = 10.0 if N >= 50 else 1.0
+    rng = np.random.default_rng(nB * 100 + N)
+    tspan = oracle.linspace(0, T, N + 1) if N != 64 else np.concatenate([[0.0], np.sort(rng.uniform(0, T, N - 1)), [T]])
+    g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    Cg, Co = (ocs.PWLinearControl, oracle.PWLinearControl) if kind == "lin" else (ocs.PWConstantControl, oracle.PWConstantControl)
+    cg, co = Cg(g.t, nB, 1), Co(go.t, nB, 1)
+    free = [nS, 1] if nS > 1 else [1]
+    V = np.vstack([rng.uniform(0.05, 0.45, (nB, batch)), rng.uniform(0.8, 1.6, (len(free), batch))])
+    cs = rng.uniform(1.0, 2.0, batch)
+    x0 = rng.uniform(0.8, 1.5, (nS, batch))
+    pg = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    pg.set_batch_params([0], cs[None, :])
+    out = {}
+    for mode in ("on", "off"):
+        cg.set_fusion(mode)
+        out[mode] = ocs.nlp_objective(g, pg, cg, x0.copy(), V, FreeInitStates=free)
+    Jf, df, x0f = out["on"]
+    Ju, du, x0u = out["off"]
+    assert relerr(Jf, Ju) < 1e-13 and relerr(df, du) < RTOL and np.array_equal(x0f, x0u)
+    for b in sorted({0, batch // 2, batch - 1}):
+        po = oracle.LogisticProblem(m, cs[b], P["r"], BOUNDS)
+        Jo, do, x0o = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b], FreeInitStates=free)
+        assert abs(Jf[b] - Jo) < RTOL * max(1.0, abs(Jo)) and relerr(df[:, b], do) < RTOL
+    cg.set_fusion("auto")
