@@ -348,7 +348,6 @@ template <class P, bool OUT_LAM, bool OUT_DJDU>
 __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   constexpr int G = P::NS, NAUG = P::NAUG;
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
-  static_assert(G >= 2, "the backward pipeline needs the LDS of a CU for G >= 2 (see DESIGN.md)");
   using C_ = PLCfg<G, true>;
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
   constexpr int UOFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::U_DBL;
@@ -605,7 +604,6 @@ bool pipeline_supported(Functor f, int nS, int nC) {
   return f == Functor::Logistic && (nS == 1 || nS == 2 || nS == 4) && nC == 1;
 }
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward) {
-  if (backward && nS < 2) return false;
   const int D = 8, TPW = 64 / nS;
   (void)backward;
   return N >= D && N % D == 0 && batch % TPW == 0;
@@ -687,7 +685,9 @@ int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const
   (void)hipMemsetAsync(dbgb, 0, sizeof(long long) * 16 * nwg, s);
   a.dbg = dbgb;
 #endif
-  if (p.nS == 2)
+  if (p.nS == 1)
+    run_backward_pl<LogisticK<1>>(a, s);
+  else if (p.nS == 2)
     run_backward_pl<LogisticK<2>>(a, s);
   else if (p.nS == 4)
     run_backward_pl<LogisticK<4>>(a, s);

@@ -271,3 +271,29 @@ def test_full_size_properties_bl2(ocs, oracle):
     b = g.compute_adjoints(pg, u, l2, nargout=1)
     c = g.compute_adjoints(pg, u, l1 + l2, nargout=1)
     assert relerr(a + b, c) < 1e-11
+
+
+@pytest.mark.parametrize("N,batch,T", [(1000, 64, 10.0), (24, 128, 1.0), (37, 64, 1.5), (8, 192, 0.4)])
+def test_single_state_pipeline_adjoint(ocs, oracle, N, batch, T):
+    # nS = 1 (TestOCProblem itself): the wave-specialised kernels with one lane per trajectory, forward and adjoint,
+    # including a step count that is not a multiple of the block length, explicit lamT and the lam-only / dJdu-only variants
+    tspan, x0, u = _inputs(oracle, 1, N, batch, seed=900 + N, T=T)
+    pg, po = ocs.TestOCProblem(P, BOUNDS), oracle.TestOCProblem(P, BOUNDS)
+    g = ocs.RK4Integrator(tspan).set_mapping("pipeline")
+    x, J = g.compute_states(pg, x0, u)
+    lam, dJdu = g.compute_adjoints(pg, u)
+    ref = oracle.batch_states_adjoints(po, tspan, x0, u)
+    assert relerr(x, ref["x"]) < RTOL and relerr(J, ref["J"]) < RTOL
+    assert relerr(lam, ref["lam"]) < RTOL and relerr(dJdu, ref["dJdu"]) < RTOL
+    assert np.all(lam[-1] == 1.0)
+    gl = ocs.RK4Integrator(tspan).set_mapping("lane")
+    gl.compute_states(pg, x0, u)
+    laml, dl = gl.compute_adjoints(pg, u)
+    assert relerr(lam, laml) < 1e-13 and relerr(dJdu, dl) < 1e-13
+    lamT = np.random.default_rng(2).normal(size=(2, batch))
+    g.compute_states(pg, x0, u)
+    lam2 = g.compute_adjoints(pg, u, lamT, nargout=1)
+    go = oracle.RK4Integrator(tspan)
+    for b in (0, batch - 1):
+        go.compute_states(po, x0[:, b], u[:, :, b])
+        assert relerr(lam2[:, :, b], go.compute_adjoints(po, u[:, :, b], lamT[:, b], want_dJdu=False)) < RTOL
