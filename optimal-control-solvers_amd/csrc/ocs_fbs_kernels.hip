@@ -48,6 +48,9 @@ static void run_costate(const CostateArgs& a, hipStream_t s) {
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb) {
   if (frozen && !dump) return -1;
+  // the wave-specialised kernel while its workgroups (one per 64/nS instances) fit on the chip in two rounds
+  if (costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) && batch / (64 / p.nS) <= 512)
+    return launch_costate_pl(p, g, batch, x, ldx, xmid, frozen, dump, lam, ldb, s);
   const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam, ldb};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};

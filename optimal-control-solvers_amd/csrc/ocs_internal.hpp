@@ -40,6 +40,10 @@ enum Mapping : int { MAP_AUTO = 0, MAP_LANE = 1, MAP_ROWSPLIT = 2, MAP_PIPELINE 
 bool pipeline_supported(Functor f, int nS, int nC);
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward);  // nSTEPS multiple of the block, batch of the tile
 int pipeline_block_steps();  // the pipeline kernels take whole blocks of this many steps
+// wave-specialised costate pass of the sweep (registry problems whose adjoint right-hand side does not read u)
+bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch);
+int launch_costate_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
+                      const int* frozen, double* dump, double* lam, int ld, hipStream_t s);
 // pend0: optional [B], the k1 half of column 2N of dJdu when the steps above N were integrated by another kernel
 int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                        const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,

@@ -189,15 +189,17 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
     }, r);
     // a frozen trajectory writes every value to one scratch double (pointer stride 0): no branch around stores
     // (FRZ is a template parameter: without frozen lanes the column stride stays a scalar)
+    // frozen trajectories skip their stores (a scratch address written a thousand times by the same lane was
+    // measured to cost up to 60 % of the kernel once most instances are frozen)
     const bool fz = FRZ && a.frozen[b] != 0;
-    const size_t colB = (FRZ && fz) ? 0 : (size_t)NAUG * B;
+    const size_t colB = (size_t)NAUG * B;
     const double u0 = a.u[b];
     if (wave == 1) {
       // ---------------- S: state recursion ----------------
       double y = a.x0[(size_t)r * B + b];
       double uprev = u0;
-      double* xs = fz ? a.dump + b : a.x + (size_t)r * B + b;
-      if (OUT_X) *xs = y;
+      double* xs = a.x + (size_t)r * B + b;
+      if (OUT_X && !fz) *xs = y;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
         const long long t0 = PL_T();
@@ -240,7 +242,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
             if (OUT_X) {
               xs += colB;
-              *xs = y;
+              if (!fz) *xs = y;
             }
             uprev = c.uB;
           }
@@ -259,8 +261,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       // pc += W_A q1 + W_M (q2 + q3) + W_B q4 with the quadrature weights of the record table
       // (W_A = h/6 e^{-r t_A}, ...): the same sum as h/6 (F1 + 2 F2 + 2 F3 + F4) of the cost row.
       double pc = 0.0, uprev2 = u0 * u0;
-      double* xc = fz ? a.dump + b : a.x + (size_t)G * B + b;
-      if (OUT_X) *xc = 0.0;
+      double* xc = a.x + (size_t)G * B + b;
+      if (OUT_X && !fz) *xc = 0.0;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
         const long long t0 = PL_T();
@@ -298,7 +300,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             pc = __builtin_fma(c.wA, q1, __builtin_fma(c.wM, q2 + q3, __builtin_fma(c.wB, q4, pc)));
             if (OUT_X) {
               xc += colB;
-              *xc = group_sum_pl<G>(pc);
+              const double pcs = group_sum_pl<G>(pc);
+              if (!fz) *xc = pcs;
             }
             uprev2 = uB2;
           }
@@ -598,6 +601,159 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   }
 }
 
+
+// ---------------------------------------------------------------------------------------
+// costate pass of the forward-backward sweep (compute_x_lam.m:11-14 on the node grid): lam' = adjointRHS(t, x(t),
+// lam, u(t)), lam(TF) = 0, classical RK4 from TF down to T0 with x at the nodes and the pchip midpoints.
+// Two waves: M streams the step records, x(t_i) and x(tmid_i) of a block into LDS with LDS-DMA, Q blocks ahead;
+// L runs the recursion out of LDS and stores lam.  For the row-separable registry problems the adjoint right-hand
+// side does not read u, so no control samples are moved.  Blocks are numbered from TF: block j covers steps
+// i = N-1-j*D-s, s = 0..D-1.  barrier_k, k = 0..nb: M waits for block k, then both waves meet; L processes block k
+// in interval k while M issues block k+Q.  Slot (k+Q) % NSLOT was last read by L in interval k+Q-NSLOT = k-1.
+// ---------------------------------------------------------------------------------------
+bool pipeline_supported(Functor f, int nS, int nC);
+template <int G>
+struct CostateCfg {
+  static constexpr int D = 8, TPW = 64 / G, Q = 3, NSLOT = Q + 1;
+  static constexpr int RS = rec_stride(1), SCO = rec_sc_offset(1);
+  static constexpr int REC_DBL = D * RS, NREC = REC_DBL / 128;
+  static constexpr int X_DBL = D * 64, NX = X_DBL / 128;          // x(t_i) rows of a block, [step][row][traj]
+  static constexpr int SLOT = REC_DBL + 2 * X_DBL;               // + the midpoint rows
+  static constexpr int LPB = NREC + 2 * NX;
+};
+struct CostateArgsPL {
+  int N, batch, ld;       // ld: row distance of the arrays (window of a larger batch) or 0
+  const double* REC;
+  const double* ps;
+  const double* pb;
+  unsigned pmask;
+  const double* x;        // [N+1][ldx][B]
+  int ldx;
+  const double* xmid;     // [N][G][B]
+  const int* frozen;
+  double* dump;
+  double* lam;            // [N+1][G][B]
+};
+
+template <class P, bool FRZ>
+__global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
+  constexpr int G = P::NS;
+  static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
+  using C_ = CostateCfg<G>;
+  constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS;
+  constexpr int XOFF = C_::REC_DBL, MOFF = C_::REC_DBL + C_::X_DBL;
+  __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const size_t B = (size_t)(a.ld ? a.ld : a.batch);
+  const int N = a.N, nb = N / D;
+  const int bw = blockIdx.x * TPW;
+  if (wave == 0) {
+    // ---------------- M: HBM -> LDS ----------------
+    auto issue = [&](int j) OCS_INLINE {
+      double* dst = &inp[j % NSLOT][0];
+      const int iLo = N - (j + 1) * D;  // lowest step of the block; LDS holds ascending steps
+#pragma unroll
+      for (int q = 0; q < C_::NREC; ++q) dma16(a.REC + (size_t)iLo * RS + q * 128 + 2 * lane, dst + q * 128);
+#pragma unroll
+      for (int q = 0; q < C_::NX; ++q) {
+        const int e = q * 128 + 2 * lane, st = e / 64, rr = (e % 64) / TPW, tl = e % TPW;
+        dma16(a.x + ((size_t)(iLo + st) * a.ldx + rr) * B + bw + tl, dst + XOFF + q * 128);
+        dma16(a.xmid + ((size_t)(iLo + st) * G + rr) * B + bw + tl, dst + MOFF + q * 128);
+      }
+    };
+    for (int j = 0; j < Q && j < nb; ++j) issue(j);
+    for (int k = 0; k <= nb; ++k) {
+      if (k < nb) {
+        const int behind = (nb - 1 - k) < (Q - 1) ? (nb - 1 - k) : (Q - 1);
+        wait_blocks<C_::LPB>(behind);
+      }
+      lds_barrier();
+      if (k + Q < nb) issue(k + Q);
+    }
+    return;
+  }
+  // ---------------- L: costate recursion ----------------
+  const int r = lane % G, tl = lane / G;
+  const int b = bw + tl;
+  const uniform_ptr PS = as_uniform(a.ps);
+  const typename P::RowPar rp = P::load_row([&](int k) OCS_INLINE {
+    return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+  }, r);
+  const bool fz = FRZ && a.frozen[b] != 0;  // frozen instances skip their stores
+  const size_t colB = (size_t)G * B;
+  double* ls = a.lam + (size_t)N * G * B + (size_t)r * B + b;
+  double l = 0.0;                                           // lam0 = 0*x0   compute_x_lam.m:4
+  double xB = a.x[((size_t)N * a.ldx + r) * B + b];         // x(t_N)
+  if (!fz) *ls = 0.0;
+  for (int k = 0; k <= nb; ++k) {
+    lds_barrier();
+    if (k < nb) {
+      const double* slot = &inp[k % NSLOT][0];
+      const double* xs = slot + XOFF + r * TPW + tl;
+      const double* ms = slot + MOFF + r * TPW + tl;
+      struct In { double h, hh, h6, eA, eM, eB, xA, xM; };
+      auto fetch = [&](int s) OCS_INLINE {  // s-th step processed = local ascending index D-1-s
+        const int q = D - 1 - s;
+        In v;
+        v.h = slot[RS * q];
+        v.hh = slot[RS * q + 1];
+        v.h6 = slot[RS * q + 2];
+        v.eA = slot[RS * q + 4];
+        v.eM = slot[RS * q + 5];
+        v.eB = slot[RS * q + 6];
+        v.xA = xs[q * 64];
+        v.xM = ms[q * 64];
+        return v;
+      };
+      In nxt = fetch(0);
+#pragma unroll
+      for (int s = 0; s < D; ++s) {
+        const In c = nxt;
+        if (s + 1 < D) nxt = fetch(s + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        // adjointRHS(t, x, lam) = -dFdx_times_vec(t, [x;0], u, [lam;1])(row r); ev = 2 e^{-rt} * 1
+        const double k1 = -P::row_dfdx(xB, l, 2.0 * c.eB, rp);
+        double L = __builtin_fma(-c.hh, k1, l);
+        const double k2 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+        L = __builtin_fma(-c.hh, k2, l);
+        const double k3 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+        L = __builtin_fma(-c.h, k3, l);
+        const double k4 = -P::row_dfdx(c.xA, L, 2.0 * c.eA, rp);
+        l = __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)) + k4, l);
+        ls -= colB;
+        if (!fz) *ls = l;
+        xB = c.xA;
+      }
+    }
+  }
+}
+
+bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch) {
+  return pipeline_supported(f, nS, nC) && N >= 8 && N % 8 == 0 && batch % (64 / nS) == 0;
+}
+template <class P>
+static void run_costate_pl(const CostateArgsPL& a, hipStream_t s) {
+  const dim3 grid(a.batch / (64 / P::NS)), block(128);
+  if (a.frozen)
+    k_costate_pl<P, true><<<grid, block, 0, s>>>(a);
+  else
+    k_costate_pl<P, false><<<grid, block, 0, s>>>(a);
+}
+int launch_costate_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
+                      const int* frozen, double* dump, double* lam, int ld, hipStream_t s) {
+  if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || (frozen && !dump)) return -1;
+  const CostateArgsPL a{g.N, batch, ld, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, frozen, dump, lam};
+  if (p.nS == 1)
+    run_costate_pl<LogisticK<1>>(a, s);
+  else if (p.nS == 2)
+    run_costate_pl<LogisticK<2>>(a, s);
+  else if (p.nS == 4)
+    run_costate_pl<LogisticK<4>>(a, s);
+  else
+    return -1;
+  return hip_rc5(hipGetLastError());
+}
 
 // ---------------------------------------------------------------------------------------
 bool pipeline_supported(Functor f, int nS, int nC) {
