@@ -189,8 +189,10 @@ typedef struct ocs_fbs_options {
   int nSWEEPS;     /* :20 */
   int nERROR_PTS;  /* :21 */
   int nINTERP_PTS; /* :22 */
-  int fused_update_off; /* build option, default 0: with the error points on the grid nodes the costate pass, the control
-                           update and the convergence metric run as one kernel; 1 keeps them separate (same results) */
+  int fused_update_off; /* build option, default 0: with the error points on the grid nodes the convergence metric is
+                           taken inside the control update, and the pchip midpoints of x are formed inside the costate
+                           and control kernels; 1 keeps all of them separate kernels, 2 only the midpoints (same
+                           results to round-off) */
   int nWINDOWS;         /* build option, default 0 = automatic (currently 1): with the fused update the batch can be cut
                            into this many windows that run their sweep loops on separate streams (marching kernels of
                            one window under the streaming kernels of another); results do not depend on it */

@@ -9,7 +9,7 @@ using namespace ocs;
 
 struct ocs_fbs_state {
   // pchip node tables
-  DevBuf TN, HN, W1, W2, TM, IH;
+  DevBuf TN, HN, W1, W2, TM, IH, PR;
   bool tables = false;
   // query-point tables (error points / interp points), rebuilt when the options change
   int nerr = 0, nint = 0;
@@ -30,7 +30,7 @@ struct ocs_fbs_state {
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
   if (!s) return;
-  DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->IH, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
+  DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->IH, &s->PR, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
                     &s->TI, &s->TUI, &s->xaug, &s->xmid, &s->lam, &s->lmid, &s->ugrid, &s->uerr, &s->uint_, &s->J,
                     &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage, &s->metric, &s->anyvalid, &s->dump};
   for (DevBuf* b : bufs) b->release();
@@ -83,13 +83,31 @@ static int ensure_tables(ocs_integrator_s* g) {
   std::vector<double> ih(N);
   for (int i = 0; i < N; ++i) ih[i] = 1.0 / h[i];
   OCS_TRY(upload(f->IH, ih.data(), sizeof(double) * N));
+  {  // per-interval records: {h(i-1),h(i),h(i+1), their reciprocals, W1(i),W2(i),W1(i+1),W2(i+1), tmid-t(i), pad}
+    const int R = costate_prec();
+    std::vector<double> pr((size_t)N * R, 0.0);
+    auto cl = [&](int k) { return k < 0 ? 0 : (k > N - 1 ? N - 1 : k); };
+    for (int i = 0; i < N; ++i) {
+      double* q = &pr[(size_t)i * R];
+      for (int e = 0; e < 3; ++e) {
+        q[e] = h[cl(i - 1 + e)];
+        q[3 + e] = ih[cl(i - 1 + e)];
+      }
+      q[6] = w1[i];
+      q[7] = w2[i];
+      q[8] = w1[i + 1];
+      q[9] = w2[i + 1];
+      q[10] = tm[i] - tn[i];
+    }
+    OCS_TRY(upload(f->PR, pr.data(), sizeof(double) * pr.size()));
+  }
   f->tables = true;
   return OCS_OK;
 }
 
 static FbsTables tabs(const ocs_integrator_s* g) {
   const ocs_fbs_state* f = g->fbs;
-  return FbsTables{g->N + 1, f->TN.d(), f->HN.d(), f->W1.d(), f->W2.d(), f->TM.d(), f->IH.d()};
+  return FbsTables{g->N + 1, f->TN.d(), f->HN.d(), f->W1.d(), f->W2.d(), f->TM.d(), f->IH.d(), f->PR.d()};
 }
 
 // interval index and local coordinate of query points linspace(T0, TF, nq)
@@ -163,7 +181,12 @@ int ocs_compute_x_lam_dev(ocs_integrator g, ocs_problem p, int batch, const doub
     Jd = f->J.d();
   }
   LAUNCH_TRY(launch_forward(describe(p), describe(g), batch, x0, ugrid, xaug, Jd, FwdOpts(), s));
-  LAUNCH_TRY(launch_pchip_mid(tabs(g), nS, nAug, batch, xaug, f->xmid.d(), s));
+  const FbsTables tb = tabs(g);
+  if (costate_forms_midpoints(describe(p), N, batch)) {  // pchip midpoints of x inside the costate kernel
+    LAUNCH_TRY(launch_costate(describe(p), describe(g), batch, xaug, nAug, nullptr, ugrid, nullptr, 0, lam, s, 0, tb.PR));
+    return OCS_OK;
+  }
+  LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
   LAUNCH_TRY(launch_costate(describe(p), describe(g), batch, xaug, nAug, f->xmid.d(), ugrid, nullptr, 0, lam, s));
   return OCS_OK;
 }
@@ -221,7 +244,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // Error points on the grid nodes and the default start: the control at the error points is the node samples of the
   // grid control, so the weighted change is taken while the grid control is replaced (one kernel, one pass over x and
   // lam) instead of in a separate error-point kernel with its own copy of the control.
-  const bool fusedup = f->err_on_nodes && !u0grid && opt->fused_update_off == 0;
+  const bool fusedup = f->err_on_nodes && !u0grid && opt->fused_update_off != 1;
   const int nparts = fusedup ? control_grid_parts(N) : control_pts_parts(nE);
   OCS_TRY(f->metric.ensure(sizeof(double) * (size_t)nparts * B));
   OCS_TRY(f->anyvalid.ensure(sizeof(int) * B));
@@ -340,14 +363,17 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     fo.frozen = status;
     fo.dump = f->dump.d();
     LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
-    LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
+    // pchip midpoints of x: inside the costate and control kernels where the wave-specialised costate kernel applies
+    const bool ownx = fusedup && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch);
+    const double* xmid = ownx ? nullptr : f->xmid.d();
+    if (!ownx) LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
     HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));
     if (fusedup) {
       // costate (:95); uNew = ControlChar(t, x(t), lam(t)) on the grid, in place (:96, :85), with the weighted change at
       // the nodes (:107) folded in.  A just-converged instance takes uNew as well, but it is frozen from now on: its
       // x, lam, J are the ones computed above from the old control, which is what final_sweep(u) returns (:82).
-      LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), status, f->dump.d(), lam, s));
-      LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, f->xmid.d(), lam, f->ugrid.d(), status, f->metric.d(),
+      LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, xmid, f->ugrid.d(), status, f->dump.d(), lam, s, 0, tb.PR));
+      LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, xmid, lam, f->ugrid.d(), status, f->metric.d(),
                                      opt->uRelTol, opt->uAbsTol, s));
       LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
                                     mc, (int*)f->nactive.p, s));

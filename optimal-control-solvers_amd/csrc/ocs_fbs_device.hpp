@@ -383,6 +383,12 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   double lmid[NS][R];
 #pragma unroll
   for (int k = 0; k < NS; ++k) pchip_mid_run<R>(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i0, a.TM, lmid[k]);
+  const bool ownx = a.xmid == nullptr;  // no midpoint array of x: form those here as well
+  double xmr[NS][R];
+  if (ownx) {
+#pragma unroll
+    for (int k = 0; k < NS; ++k) pchip_mid_run<R>(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i0, a.TM, xmr[k]);
+  }
   double wmax = 0.0;
   bool any = false;
   auto emit = [&](int j, const double* x, const double* lam) OCS_INLINE {  // grid point j
@@ -417,7 +423,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
       emit(2 * i, x, lam);
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        x[k] = a.xmid[((size_t)i * NS + k) * B + b];
+        x[k] = ownx ? xmr[k][c] : a.xmid[((size_t)i * NS + k) * B + b];
         lam[k] = lmid[k][c];
       }
       emit(2 * i + 1, x, lam);

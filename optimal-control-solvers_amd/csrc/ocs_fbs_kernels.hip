@@ -41,16 +41,23 @@ int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const dou
   return hip_rc3(hipGetLastError());
 }
 
+// whether launch_costate takes xmid == NULL (with PR) and forms the pchip midpoints of x itself
+bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch) {
+  return costate_pl_ok(p.functor, p.nS, p.nC, N, batch) && batch / (64 / p.nS) <= 512;
+}
 template <class P>
 static void run_costate(const CostateArgs& a, hipStream_t s) {
   k_costate<P, 4><<<dim3((a.batch + 63) / 64), dim3(64), 0, s>>>(a);
 }
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
-                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb) {
+                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb,
+                   const double* PR) {
   if (frozen && !dump) return -1;
   // the wave-specialised kernel while its workgroups (one per 64/nS instances) fit on the chip in two rounds
-  if (costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) && batch / (64 / p.nS) <= 512)
-    return launch_costate_pl(p, g, batch, x, ldx, xmid, frozen, dump, lam, ldb, s);
+  if (costate_forms_midpoints(p, g.N, batch))
+    return xmid ? launch_costate_pl(p, g, batch, x, ldx, xmid, frozen, dump, lam, ldb, s)
+                : launch_costate_plx(p, g, batch, x, ldx, PR, frozen, dump, lam, ldb, s);
+  if (!xmid) return -1;
   const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam, ldb};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};

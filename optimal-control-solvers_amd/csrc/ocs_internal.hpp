@@ -42,6 +42,10 @@ bool pipeline_shape_ok(int nS, int N, int batch, bool backward);  // nSTEPS mult
 int pipeline_block_steps();  // the pipeline kernels take whole blocks of this many steps
 // wave-specialised costate pass of the sweep (registry problems whose adjoint right-hand side does not read u)
 bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch);
+// the same forming the pchip midpoints of x itself (no xmid array); PR: [N][costate_prec()] interval records
+int costate_prec();
+int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s);
 int launch_costate_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s);
 // pend0: optional [B], the k1 half of column 2N of dJdu when the steps above N were integrated by another kernel
@@ -134,12 +138,15 @@ struct FbsTables {   // pchip node tables of an integrator grid, device pointers
   const double* W2;
   const double* TM;  // [n-1] interval midpoints
   const double* IH;  // [n-1] reciprocal spacings
+  const double* PR;  // [n-1][costate_prec()] per-interval pchip records (launch_costate_plx)
 };
 // ldb: row distance of V / out when the call covers a window of a larger batch (0 = batch)
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s,
                      int ldb = 0);
+bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
-                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb = 0);
+                   const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb = 0,
+                   const double* PR = nullptr);  // xmid == NULL with PR: the kernel forms the midpoints (see below)
 // metric (optional): [control_grid_parts(N)][B] partial maxima of the weighted change at the grid nodes (error points
 // == nodes), for launch_fbs_advance
 int control_grid_parts(int N);

@@ -729,6 +729,243 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------
+// The same costate pass forming the pchip midpoints x(tmid_i) itself: four more waves (H0..H3) evaluate them for
+// the block the recursion wave takes next, out of the x(t_i) rows M has already put into LDS (each takes two
+// consecutive intervals, so a node slope shared by two of them is computed once).  The separate midpoint kernel and
+// the round trip of its output through memory disappear (waves 1, 2, 4, 5; the recursion wave is wave 3, alone on its SIMD).  Per-interval pchip constants come from a record table
+// (PR: spacings, their reciprocals, slope weights, local midpoint) that M streams with the step records.
+//   interval k (between barriers k and k+1):  M: issue block k+Q (block k+1 has landed);  H: block k-1;  L: block k-2
+//   slot of block j is read in intervals j (one node, by H for block j-1), j+1 (H), j+2 (two nodes by H for block
+//   j+1; L) and rewritten by M in interval j+NSLOT-Q  ->  NSLOT = Q + 3.
+// ---------------------------------------------------------------------------------------
+constexpr int kPRec = 16;  // doubles per interval record {h(i-1),h(i),h(i+1), 1/h x3, W1(i),W2(i),W1(i+1),W2(i+1), tmid-t(i), pad}
+template <int G>
+struct CostateXCfg {
+  static constexpr int D = 8, TPW = 64 / G, Q = 3, NSLOT = Q + 3;
+  static constexpr int RS = rec_stride(1);
+  static constexpr int REC_DBL = D * RS, NREC = REC_DBL / 128;
+  static constexpr int PR_DBL = D * kPRec, NPR = PR_DBL / 128;
+  static constexpr int X_DBL = D * 64, NX = X_DBL / 128;
+  static constexpr int SLOT = REC_DBL + PR_DBL + X_DBL;
+  static constexpr int LPB = NREC + NPR + NX;
+  static_assert(PR_DBL % 128 == 0, "interval records of a block must be whole DMA instructions");
+};
+struct CostateXArgs {
+  CostateArgsPL c;     // c.xmid is not used
+  const double* PR;    // [N][kPRec]
+};
+
+// interior slope with ONE division: |del0 del1| / (w1 |del0| + w2 |del1|) (pchip_interior's harmonic mean multiplied
+// through by dmax; round-off level difference to the two-division form of the midpoint kernel)
+__device__ static inline double pchip_interior1(double del0, double del1, double w1, double w2) {
+  const bool same = (del0 > 0.0 && del1 > 0.0) || (del0 < 0.0 && del1 < 0.0);
+  const double a0 = fabs(del0), a1 = fabs(del1);
+  double d = (a0 * a1) / __builtin_fma(w1, a0, w2 * a1);
+  asm volatile("" : "+v"(d));  // keep the division out of a divergent branch (0/0 lanes are discarded below)
+  return same ? (del0 > 0.0 ? d : -d) : 0.0;
+}
+__device__ static inline double pchip_end_pl(double h0, double h1, double del0, double del1) {
+  double d = ((2.0 * h0 + h1) * del0 - h0 * del1) / (h0 + h1);
+  const bool s0 = (d > 0.0) == (del0 > 0.0) && (d < 0.0) == (del0 < 0.0);
+  const bool s1 = (del0 > 0.0) == (del1 > 0.0) && (del0 < 0.0) == (del1 < 0.0);
+  if (!s0)
+    d = 0.0;
+  else if (!s1 && fabs(d) > fabs(3.0 * del0))
+    d = 3.0 * del0;
+  return d;
+}
+
+// one helper wave of k_costate_plx: the pchip midpoints of intervals q0 .. q0+RL-1 (ascending positions) of every block
+template <class C_, int RL>
+__device__ static inline void costate_midpoints(const double (*inp)[C_::SLOT], double (*xm)[C_::D][64], int q0, int N,
+                                                int r, int tl, int lane, double xN) {
+  constexpr int D = C_::D, TPW = C_::TPW, NSLOT = C_::NSLOT;
+  constexpr int POFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::PR_DBL;
+  const int nb = N / D;
+  for (int k = 0; k <= nb + 1; ++k) {
+    lds_barrier();
+    const int j = k - 1;
+    if (j < 0 || j >= nb) continue;
+    const double* slot = &inp[0][0] + C_::SLOT * (j % NSLOT);
+    const int iLo = N - (j + 1) * D;
+    // Straight-line on purpose (no branch between the LDS reads, all slopes as interior ones behind an opaque
+    // barrier): the three divisions then overlap; written with branches this wave took longer than the recursion.
+    // records of the run
+    double pr[RL][11];
+#pragma unroll
+    for (int c = 0; c < RL; ++c)
+#pragma unroll
+      for (int e = 0; e < 11; ++e) pr[c][e] = slot[POFF + (q0 + c) * kPRec + e];
+    // nodes iLo+q0-1 .. iLo+q0+RL+1 of this lane's row (ascending): own block, one node of the block below
+    // (j+1), two of the block above (j-1) or x(t_N); a node outside the grid reads some valid address instead
+    double w[RL + 3];
+#pragma unroll
+    for (int t = 0; t < RL + 3; ++t) {
+      const int q = q0 - 1 + t;  // position relative to this block
+      const int jj = q < 0 ? (j + 1 < nb ? j + 1 : j) : (q < D ? j : (j > 0 ? j - 1 : j));
+      const int qq = q < 0 ? D + q : (q < D ? q : q - D);
+      const double v = (&inp[0][0] + C_::SLOT * (jj % NSLOT) + XOFF + r * TPW + tl)[qq * 64];
+      w[t] = (q >= D && j == 0) ? xN : v;
+    }
+    double sec[RL + 2];  // secants of intervals iLo+q0-1 .. iLo+q0+RL
+#pragma unroll
+    for (int t = 0; t < RL + 2; ++t) {
+      const double ih = t == 0 ? pr[0][3] : (t == RL + 1 ? pr[RL - 1][5] : pr[t - 1][4]);
+      sec[t] = (w[t + 1] - w[t]) * ih;
+    }
+    double d[RL + 1];  // slopes at nodes iLo+q0 .. iLo+q0+RL
+#pragma unroll
+    for (int c = 0; c < RL + 1; ++c) {
+      d[c] = pchip_interior1(sec[c], sec[c + 1], c < RL ? pr[c][6] : pr[RL - 1][8], c < RL ? pr[c][7] : pr[RL - 1][9]);
+    }
+    if (iLo + q0 == 0) d[0] = pchip_end_pl(pr[0][1], pr[0][2], sec[1], sec[2]);
+    if (iLo + q0 + RL == N) d[RL] = pchip_end_pl(pr[RL - 1][1], pr[RL - 1][0], sec[RL], sec[RL - 1]);
+    double* out = &xm[j & 1][0][lane];
+#pragma unroll
+    for (int c = 0; c < RL; ++c) {
+      const double ih0 = pr[c][4], sv = pr[c][10], sb = sec[c + 1];
+      const double dzzdx = (sb - d[c]) * ih0, dzdxdx = (d[c + 1] - sb) * ih0;
+      const double c3 = (dzdxdx - dzzdx) * ih0, c2 = 2.0 * dzzdx - dzdxdx;
+      out[(q0 + c) * 64] = w[c + 1] + sv * (d[c] + sv * (c2 + sv * c3));
+    }
+  }
+}
+
+template <class P, bool FRZ>
+__global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
+  constexpr int G = P::NS;
+  static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
+  using C_ = CostateXCfg<G>;
+  constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS;
+  constexpr int POFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::PR_DBL;
+  const CostateArgsPL& a = aa.c;
+  __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];
+  __shared__ __attribute__((aligned(16))) double xm[2][D][64];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const size_t B = (size_t)(a.ld ? a.ld : a.batch);
+  const int N = a.N, nb = N / D;
+  const int bw = blockIdx.x * TPW;
+  if (wave == 0) {
+    // ---------------- M: HBM -> LDS ----------------
+    auto issue = [&](int j) OCS_INLINE {
+      double* dst = &inp[j % NSLOT][0];
+      const int iLo = N - (j + 1) * D;
+#pragma unroll
+      for (int q = 0; q < C_::NREC; ++q) dma16(a.REC + (size_t)iLo * RS + q * 128 + 2 * lane, dst + q * 128);
+#pragma unroll
+      for (int q = 0; q < C_::NPR; ++q) dma16(aa.PR + (size_t)iLo * kPRec + q * 128 + 2 * lane, dst + POFF + q * 128);
+#pragma unroll
+      for (int q = 0; q < C_::NX; ++q) {
+        const int e = q * 128 + 2 * lane, st = e / 64, rr = (e % 64) / TPW, tl = e % TPW;
+        dma16(a.x + ((size_t)(iLo + st) * a.ldx + rr) * B + bw + tl, dst + XOFF + q * 128);
+      }
+    };
+    for (int j = 0; j < Q && j < nb; ++j) issue(j);
+    for (int k = 0; k <= nb + 1; ++k) {
+      if (k < nb) {
+        const int behind = (nb - 1 - k) < (Q - 1) ? (nb - 1 - k) : (Q - 1);
+        wait_blocks<C_::LPB>(behind);
+      }
+      lds_barrier();
+      if (k + Q < nb) issue(k + Q);
+    }
+    return;
+  }
+  const int r = lane % G, tl = lane / G;
+  const int b = bw + tl;
+  const double xN = a.x[((size_t)N * a.ldx + r) * B + b];  // x(t_N): the node above the first block
+  if (wave != 3) {
+    // ---------------- H0, H1, H2: pchip midpoints of intervals 0-2, 3-5, 6-7 of every block ----------------
+    // (waves 1, 2, 4: one per SIMD beside the recursion wave's; two helpers on one SIMD were the bottleneck)
+    if (wave == 1)
+      costate_midpoints<C_, 3>(inp, xm, 0, N, r, tl, lane, xN);
+    else if (wave == 2)
+      costate_midpoints<C_, 3>(inp, xm, 3, N, r, tl, lane, xN);
+    else
+      costate_midpoints<C_, 2>(inp, xm, 6, N, r, tl, lane, xN);
+    return;
+  }
+  // ---------------- L: costate recursion ----------------
+  const uniform_ptr PS = as_uniform(a.ps);
+  const typename P::RowPar rp = P::load_row([&](int k) OCS_INLINE {
+    return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+  }, r);
+  const bool fz = FRZ && a.frozen[b] != 0;
+  const size_t colB = (size_t)G * B;
+  double* ls = a.lam + (size_t)N * G * B + (size_t)r * B + b;
+  double l = 0.0;
+  double xB = xN;
+  if (!fz) *ls = 0.0;
+  for (int k = 0; k <= nb + 1; ++k) {
+    lds_barrier();
+    const int j = k - 2;
+    if (j < 0) continue;
+    const double* slot = &inp[j % NSLOT][0];
+    const double* xs = slot + XOFF + r * TPW + tl;
+    const double* ms = &xm[j & 1][0][lane];
+    struct In { double h, hh, h6, eA, eM, eB, xA, xM; };
+    auto fetch = [&](int s) OCS_INLINE {
+      const int q = D - 1 - s;
+      In v;
+      v.h = slot[RS * q];
+      v.hh = slot[RS * q + 1];
+      v.h6 = slot[RS * q + 2];
+      v.eA = slot[RS * q + 4];
+      v.eM = slot[RS * q + 5];
+      v.eB = slot[RS * q + 6];
+      v.xA = xs[q * 64];
+      v.xM = ms[q * 64];
+      return v;
+    };
+    In nxt = fetch(0);
+#pragma unroll
+    for (int s = 0; s < D; ++s) {
+      const In c = nxt;
+      if (s + 1 < D) nxt = fetch(s + 1);
+      __builtin_amdgcn_sched_barrier(0);
+      const double k1 = -P::row_dfdx(xB, l, 2.0 * c.eB, rp);
+      double L = __builtin_fma(-c.hh, k1, l);
+      const double k2 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+      L = __builtin_fma(-c.hh, k2, l);
+      const double k3 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+      L = __builtin_fma(-c.h, k3, l);
+      const double k4 = -P::row_dfdx(c.xA, L, 2.0 * c.eA, rp);
+      l = __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)) + k4, l);
+      ls -= colB;
+      if (!fz) *ls = l;
+      xB = c.xA;
+    }
+  }
+}
+
+template <class P>
+static void run_costate_plx(const CostateXArgs& a, hipStream_t s) {
+  const dim3 grid(a.c.batch / (64 / P::NS)), block(320);
+  if (a.c.frozen)
+    k_costate_plx<P, true><<<grid, block, 0, s>>>(a);
+  else
+    k_costate_plx<P, false><<<grid, block, 0, s>>>(a);
+}
+int costate_prec() { return kPRec; }
+bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch);
+// PR: [N][costate_prec()] interval records; the midpoints are formed inside (no xmid array)
+int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s) {
+  if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || (frozen && !dump) || !PR) return -1;
+  const CostateXArgs a{CostateArgsPL{g.N, batch, ld, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, frozen, dump, lam}, PR};
+  if (p.nS == 1)
+    run_costate_plx<LogisticK<1>>(a, s);
+  else if (p.nS == 2)
+    run_costate_plx<LogisticK<2>>(a, s);
+  else if (p.nS == 4)
+    run_costate_plx<LogisticK<4>>(a, s);
+  else
+    return -1;
+  return hip_rc5(hipGetLastError());
+}
+
 bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch) {
   return pipeline_supported(f, nS, nC) && N >= 8 && N % 8 == 0 && batch % (64 / nS) == 0;
 }

@@ -131,7 +131,8 @@ def test_fb_sweep_full_size_properties(ocs, oracle):
 
 
 @pytest.mark.parametrize("nS,N,batch", [(1, 400, 70), (1, 37, 5), (2, 203, 130), (4, 64, 64), (3, 9, 3), (1, 8, 64),
-                                        (1, 5, 2), (1, 120, 300), (4, 48, 200)])
+                                        (1, 5, 2), (1, 120, 300), (4, 48, 200), (1, 400, 128), (2, 16, 96),
+                                        (4, 24, 48), (2, 208, 64)])
 def test_fused_costate_update_equals_separate_kernels(ocs, oracle, nS, N, batch):
     """With the error points on the grid nodes the costate pass, the in-place control update and the weighted
     change (fb_sweep.m:95-96, :107) run as one kernel (update waves trailing the marching wave through an LDS ring of
@@ -158,6 +159,11 @@ def test_fused_costate_update_equals_separate_kernels(ocs, oracle, nS, N, batch)
         # (J: a ragged last window runs the lane kernel, which sums the running objective in another order)
         assert relerr(ra["J"], rw["J"]) < 1e-13
         assert np.array_equal(np.nan_to_num(ra["maxChange"]), np.nan_to_num(rw["maxChange"]))
+    # ... and with the pchip midpoints of x from their own kernel instead of inside the costate / control kernels
+    rc = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=2))
+    assert np.array_equal(ra["sweeps"], rc["sweeps"])
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rc[key]) < 1e-12, key
     assert np.array_equal(ra["sweeps"], rb["sweeps"]) and ra["sweeps"].min() > 0
     # near convergence the weighted change is |du| ~ 1e-8 over 1e-7: one ulp in u (the reciprocal in the fused
     # ControlChar) moves it by ~1e-9 relative
