@@ -163,6 +163,11 @@ int ocs_control_eval_uFunc(ocs_control c, const double *v, int nq, const double 
 int ocs_interp(int method, int nComp, int n, const double *x, const double *v, int nq, const double *tq,
                double *out);
 
+/* the same for a batch of sample sets resident on the device (the resampling step right after the solvers,
+ * single_shooting.m:128-130, fb_sweep.m:123): x, tq host; v [n][nComp][batch] -> out [nq][nComp][batch], batch-minor */
+int ocs_interp_dev(int method, int nComp, int n, const double *x, const double *v, int nq, const double *tq,
+                   double *out, int batch, void *stream);
+
 /* [J, dJdv] = nlpObjective(v)   functions/single_shooting.m:137-150
  * v holds nC*nBasis control coefficients followed by nFree free initial states; FreeInitStates are
  * 1-based state indices (host array).  x0 is overwritten at FreeInitStates (:146).

@@ -10,7 +10,7 @@ from ._lib import OcsError  # noqa: F401
 from .problem import OCProblem, TestOCProblem, LogisticProblem, LQProblem, UserProblem  # noqa: F401
 from .integrator import Integrator, RK4Integrator, RK4InfiniteIntegrator  # noqa: F401
 from .control import Control, PWLinearControl, PWConstantControl, ChebyshevControl  # noqa: F401
-from .interp import vectorInterpolant, heval, linspace  # noqa: F401
+from .interp import vectorInterpolant, vectorInterpolant_dev, heval, linspace  # noqa: F401
 from .solvers import (nlp_objective, nlp_objective_dev, single_shooting, single_shooting_batch,  # noqa: F401
                       compute_equilibrium)
 from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, compute_x_lam, compute_x_lam_J  # noqa: F401

@@ -77,6 +77,7 @@ _SIG = {
     "ocs_control_compute_nlp_bounds": (C.c_int, [vp, dp, dp, dp]),
     "ocs_control_eval_uFunc": (C.c_int, [vp, dp, C.c_int, dp, dp]),
     "ocs_interp": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, dp, C.c_int, dp, dp]),
+    "ocs_interp_dev": (C.c_int, [C.c_int, C.c_int, C.c_int, dp, vp, C.c_int, dp, vp, C.c_int, vp]),
     "ocs_nlp_objective": (C.c_int, [vp, vp, vp, C.c_int, dp, dp, C.c_int, ip, dp, dp]),
     "ocs_nlp_objective_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, ip, vp, vp, vp]),
     "ocs_fbs_default_options": (C.c_int, [vp]),

@@ -149,6 +149,69 @@ static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBu
 
 extern "C" {
 
+// vectorInterpolant(x, v, method)(tq) for a batch of sample sets on the device (functions/vectorInterpolant.m:1-12;
+// the step right after the solvers: single_shooting.m:128-130, fb_sweep.m:123).  x [n], tq [nq] host;
+// v [n][nComp][B] -> out [nq][nComp][B] device, batch-minor.  Same rules as the host ocs_interp: 'linear' and
+// 'pchip' continue their end pieces outside the grid, 'previous' gives NaN before the first sample.
+int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* v, int nq, const double* tq,
+                   double* out, int batch, void* stream) {
+  if (!x || !v || !tq || !out || nComp < 1 || n < 2 || nq < 0 || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
+  if (method != OCS_INTERP_LINEAR && method != OCS_INTERP_PREVIOUS && method != OCS_INTERP_PCHIP)
+    return fail(OCS_ERR_UNSUPPORTED, "unknown interpolation method %d", method);
+  for (int i = 0; i + 1 < n; ++i)
+    if (!(x[i + 1] > x[i])) return fail(OCS_ERR_INVALID, "sample points must increase strictly");
+  if (nq == 0) return OCS_OK;
+  hipStream_t s = (hipStream_t)stream;
+  std::vector<double> h(n - 1), ih(n - 1), w1(n, 0.0), w2(n, 0.0), sq(nq);
+  std::vector<int> kq(nq);
+  for (int i = 0; i + 1 < n; ++i) {
+    h[i] = x[i + 1] - x[i];
+    ih[i] = 1.0 / h[i];
+  }
+  for (int k = 1; k + 1 < n; ++k) {  // pchip interior weights (MATLAB pchipslopes)
+    const double hs = h[k - 1] + h[k];
+    w1[k] = (h[k - 1] + hs) / (3 * hs);
+    w2[k] = (hs + h[k]) / (3 * hs);
+  }
+  for (int j = 0; j < nq; ++j) {
+    const double q = tq[j];
+    int lo = 0, hi = n - 1;
+    if (q <= x[0])
+      lo = 0;
+    else if (q >= x[n - 1])
+      lo = n - 2;
+    else
+      while (hi - lo > 1) {
+        const int mid = (lo + hi) / 2;
+        if (x[mid] <= q)
+          lo = mid;
+        else
+          hi = mid;
+      }
+    if (method == OCS_INTERP_PREVIOUS) lo = q < x[0] ? -1 : (q >= x[n - 1] ? n - 1 : lo);
+    kq[j] = lo;
+    sq[j] = lo >= 0 && lo < n - 1 ? q - x[lo] : 0.0;
+  }
+  DevBuf TN, HN, W1, W2, IH, KQ, SQ;  // released on return (the launch is synchronised below)
+  struct Rel {
+    DevBuf* b[7];
+    ~Rel() {
+      for (DevBuf* p : b) p->release();
+    }
+  } rel{{&TN, &HN, &W1, &W2, &IH, &KQ, &SQ}};
+  OCS_TRY(upload(TN, x, sizeof(double) * n));
+  OCS_TRY(upload(HN, h.data(), sizeof(double) * (n - 1)));
+  OCS_TRY(upload(W1, w1.data(), sizeof(double) * n));
+  OCS_TRY(upload(W2, w2.data(), sizeof(double) * n));
+  OCS_TRY(upload(IH, ih.data(), sizeof(double) * (n - 1)));
+  OCS_TRY(upload(KQ, kq.data(), sizeof(int) * nq));
+  OCS_TRY(upload(SQ, sq.data(), sizeof(double) * nq));
+  const FbsTables tb{n, TN.d(), HN.d(), W1.d(), W2.d(), nullptr, IH.d(), nullptr};
+  LAUNCH_TRY(launch_interp(method, tb, nComp, nq, (const int*)KQ.p, SQ.d(), batch, v, out, s));
+  HIP_TRY(hipStreamSynchronize(s));
+  return OCS_OK;
+}
+
 int ocs_fbs_default_options(ocs_fbs_options* o) {
   if (!o) return fail(OCS_ERR_INVALID, "null argument");
   o->uRelTol = 1e-7;      // fb_sweep.m:16

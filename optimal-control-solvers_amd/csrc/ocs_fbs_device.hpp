@@ -442,6 +442,39 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// vectorInterpolant(x, v, method)(tq) for a batch (functions/vectorInterpolant.m:1-12): out[q][c][b] from samples
+// v[node][c][b]; KQ/SQ: interval index and local coordinate of each query point (host-made, like the error points
+// of the sweep); method 0 'linear', 2 'previous' (KQ = -1: before the first node -> NaN; SQ unused), 3 'pchip'.
+// One thread takes kInterpPts consecutive query points of one (component, instance) column.
+// ---------------------------------------------------------------------------------------
+constexpr int kInterpPts = 4;
+__global__ __launch_bounds__(256) void k_interp(int method, PchipTab T, int nComp, int nq, int batch, const int* KQ,
+                                                const double* SQ, const double* V, double* out) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.z;
+  if (b >= batch) return;
+  const size_t B = (size_t)batch, ldB = (size_t)nComp * B;
+  const double* v = V + (size_t)c * B + b;
+  const int q0 = blockIdx.y * kInterpPts;
+#pragma unroll
+  for (int e = 0; e < kInterpPts; ++e) {
+    const int q = q0 + e;
+    if (q >= nq) break;
+    const int k = KQ[q];
+    double val;
+    if (method == 2) {
+      val = k < 0 ? __builtin_nan("") : v[(size_t)k * ldB];
+    } else if (method == 0) {
+      const double v0 = v[(size_t)k * ldB], v1 = v[(size_t)(k + 1) * ldB];
+      val = v0 + (v1 - v0) * (SQ[q] / T.HN[k]);
+    } else {
+      val = pchip_eval(T, v, ldB, k, SQ[q]);
+    }
+    out[((size_t)q * nComp + c) * B + b] = val;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // control at arbitrary points: out[q][c][b] = ControlChar(tq, x(tq), lam(tq)) with pchip x, lam
 // (errorPts fb_sweep.m:107, interpPts :123).  KQ/SQ: interval index and local coordinate of tq.
 // With `metric` set this is the error-point mode of the sweep: out is read (old control) and replaced in place.

@@ -122,6 +122,13 @@ int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hi
   return hip_rc3(hipGetLastError());
 }
 
+int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* KQ, const double* SQ, int batch,
+                  const double* V, double* out, hipStream_t s) {
+  k_interp<<<dim3((batch + 255) / 256, (nq + kInterpPts - 1) / kInterpPts, nComp), dim3(256), 0, s>>>(
+      method, make_tab(t), nComp, nq, batch, KQ, SQ, V, out);
+  return hip_rc3(hipGetLastError());
+}
+
 int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
                        double* maxChange, int* nactive, hipStream_t s, int ldb) {

@@ -150,6 +150,9 @@ int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const dou
 // metric (optional): [control_grid_parts(N)][B] partial maxima of the weighted change at the grid nodes (error points
 // == nodes), for launch_fbs_advance
 int control_grid_parts(int N);
+// batched vectorInterpolant: V [n][nComp][B] -> out [nq][nComp][B]; method as OCS_INTERP_*; t: tables of the sample grid
+int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* KQ, const double* SQ, int batch,
+                  const double* V, double* out, hipStream_t s);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
                         double relTol, double absTol, hipStream_t s, int ldb = 0);

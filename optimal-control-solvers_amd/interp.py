@@ -28,6 +28,30 @@ def vectorInterpolant(x, v, interpType):
     return fInterp
 
 
+def vectorInterpolant_dev(x, v, interpType):
+    """The same for a batch of sample sets resident on the device: v is a torch tensor [n][nComp][batch] (the layout
+    the *_dev solvers return); the callable maps t (k points, host) to a device tensor [k][nComp][batch]."""
+    import torch
+
+    from .integrator import _dptr, _stream
+    x = _f(x).ravel().copy()
+    method = _METHODS[interpType]
+    if v.dim() == 2:
+        v = v[:, None, :]
+    v = v.contiguous()
+    n, nComp, B = v.shape
+    if n != x.size:
+        raise ValueError("v must hold one sample per grid point")
+
+    def fInterp(t):
+        t = _f(np.atleast_1d(t)).ravel()
+        out = torch.empty((t.size, nComp, B), dtype=torch.float64, device=v.device)
+        check(lib.ocs_interp_dev(method, nComp, n, _p(x), _dptr(v), t.size, _p(t), _dptr(out), B, _stream()))
+        return out
+
+    return fInterp
+
+
 def heval(func, tspan, components):
     """functions/heval.m:1-6 (components are 0-based here)."""
     return func(tspan)[components, :]

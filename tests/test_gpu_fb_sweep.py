@@ -177,3 +177,28 @@ def test_fused_costate_update_equals_separate_kernels(ocs, oracle, nS, N, batch)
         assert abs(ra["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
         assert relerr(ra["x"][:, :, b], ref["x"]) < RTOL and relerr(ra["lam"][:, :, b], ref["lam"]) < RTOL
         assert relerr(ra["u"][:, :, b], ref["u"]) < RTOL
+
+
+@pytest.mark.parametrize("n,nComp,batch,nq", [(30, 3, 70, 211), (2, 1, 5, 9), (3, 2, 300, 17), (1001, 1, 64, 1001)])
+def test_batched_vector_interpolant_on_device(ocs, oracle, n, nComp, batch, nq):
+    """vectorInterpolant.m:1-12 for a batch of sample sets on the device (the resampling step after the solvers,
+    single_shooting.m:128-130, fb_sweep.m:123): every instance against the oracle's pchip / linear / previous,
+    query points on the nodes, between them and outside the grid."""
+    import torch
+    rng = np.random.default_rng(n + nq)
+    x = np.sort(rng.uniform(0, 5, n)) if n > 3 else np.linspace(0.0, 1.0, n)
+    v = rng.normal(size=(n, nComp, batch))
+    v[:, 0, :] = np.sin(2 * x)[:, None] * rng.uniform(0.5, 2.0, batch)[None, :]
+    if nComp > 1:
+        v[:, 1, :] = np.where(x > 2, 1.0, 0.0)[:, None]      # flat pieces and a jump: the zero-slope rule
+    q = np.concatenate([x, rng.uniform(x[0] - 0.3, x[-1] + 0.3, nq - n)]) if nq > n else rng.uniform(-0.2, 1.2, nq)
+    vd = torch.tensor(v, device="cuda:0")
+    for name, m in (("pchip", oracle.INTERP_PCHIP), ("linear", oracle.INTERP_LINEAR), ("previous", oracle.INTERP_PREVIOUS)):
+        got = ocs.vectorInterpolant_dev(x, vd, name)(q).cpu().numpy()
+        assert got.shape == (q.size, nComp, batch)
+        for b in sorted({0, batch // 2, batch - 1}):
+            ref = oracle.vector_interp(x, v[:, :, b].T, m, q)     # nComp x nq
+            # pchip / linear on device: fused multiply-adds and another order of the divisions than the oracle's loops
+            assert np.allclose(got[:, :, b].T, ref, rtol=1e-12, atol=1e-13, equal_nan=True), (name, b)
+            if name == "previous":
+                assert np.array_equal(got[:, :, b].T, ref, equal_nan=True), (name, b)
