@@ -178,6 +178,28 @@ int ocs_nlp_objective(ocs_integrator g, ocs_problem p, ocs_control c, int batch,
 int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int batch, double *x0,
                           const double *v, int nFree, const int *FreeInitStates, double *J, double *dJdv,
                           void *stream);
+/* soln = single_shooting(...) for a batch of independent problems (one per column of x0 / per parameter set),
+ * functions/single_shooting.m:69-115 with the toolbox optimiser (fmincon 'sqp', :114) replaced by a batched spectral
+ * projected gradient: Barzilai-Borwein step, projection on [Lb, Ub] (compute_nlp_bounds), non-monotone Armijo
+ * back-tracking; every instance has its own step length, line search and stopping test
+ * ||P(v - g) - v||_inf <= TolFun or ||step||_inf <= TolX; every evaluation is one nlpObjective over the batch.
+ * Iterates differ from fmincon's, the KKT point does not. */
+typedef struct {
+  double TolX;        /* single_shooting.m:20 */
+  double TolFun;      /* :21 */
+  int MaxIter;        /* outer iterations per instance */
+  int memory;         /* objective values the non-monotone line search looks back on */
+  int maxBacktracks;  /* step halvings before an instance gives up */
+} ocs_ss_options;
+int ocs_ss_default_options(ocs_ss_options *o);
+/* device arrays, batch-minor: x0 nS x batch (overwritten at FreeInitStates), v (nV+nFree) x batch: start -> solution;
+ * Lb, Ub host, nV+nFree values or NULL; J batch; iterations, converged (int), pgnorm batch or NULL.
+ * Returns OCS_NUM_NOT_CONVERGED if an instance ends with a projected gradient above 10 TolFun. */
+int ocs_single_shooting_batch_dev(ocs_integrator g, ocs_problem p, ocs_control c, int batch, double *x0, double *v,
+                                  int nFree, const int *FreeInitStates, const double *Lb, const double *Ub,
+                                  const ocs_ss_options *opt, double *J, int *iterations, int *converged,
+                                  double *pgnorm, void *stream);
+
 /* For a dense basis with at most 32 functions (ChebyshevControl) on an RK4Integrator, nlpObjective can apply
  * the basis inside the RK4 kernels (u and dJdu are never materialised).  mode: 0 automatic (large batches),
  * 1 never, 2 whenever supported.  Results are the same up to the summation order of dJdu*B'. */

@@ -81,6 +81,8 @@ _SIG = {
     "ocs_nlp_objective": (C.c_int, [vp, vp, vp, C.c_int, dp, dp, C.c_int, ip, dp, dp]),
     "ocs_nlp_objective_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, ip, vp, vp, vp]),
     "ocs_fbs_default_options": (C.c_int, [vp]),
+    "ocs_ss_default_options": (C.c_int, [vp]),
+    "ocs_single_shooting_batch_dev": (C.c_int, [vp, vp, vp, C.c_int, vp, vp, C.c_int, ip, dp, dp, vp, vp, vp, vp, vp, vp]),
     "ocs_compute_x_lam": (C.c_int, [vp, vp, C.c_int, dp, dp, dp, dp, dp]),
     "ocs_compute_x_lam_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "ocs_fb_sweep": (C.c_int, [vp, vp, C.c_int, dp, vp, dp, dp, dp, dp, dp, dp, ip, dp]),
@@ -100,6 +102,12 @@ class FbsOptions(C.Structure):
     """struct ocs_fbs_options (include/ocs.h)."""
     _fields_ = [("uRelTol", C.c_double), ("uAbsTol", C.c_double), ("nSWEEPS", C.c_int),
                 ("nERROR_PTS", C.c_int), ("nINTERP_PTS", C.c_int), ("fused_update_off", C.c_int), ("nWINDOWS", C.c_int)]
+
+
+class SsOptions(C.Structure):
+    """struct ocs_ss_options (include/ocs.h)."""
+    _fields_ = [("TolX", C.c_double), ("TolFun", C.c_double), ("MaxIter", C.c_int), ("memory", C.c_int),
+                ("maxBacktracks", C.c_int)]
 
 
 def declared_symbols():

@@ -149,6 +149,20 @@ int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const dou
                    const double* PR = nullptr);  // xmid == NULL with PR: the kernel forms the midpoints (see below)
 // metric (optional): [control_grid_parts(N)][B] partial maxima of the weighted change at the grid nodes (error points
 // == nodes), for launch_fbs_advance
+// batched single shooting (ocs_shooting.cpp): per-instance state of the spectral projected gradient iteration,
+// every array [rows][B]
+struct SpgArgs {
+  int batch, nV, memory;
+  double TolFun, TolX;
+  const double *lb, *ub;      // [nV]
+  double *v, *g, *d, *vt, *gt;  // [nV][B]: iterate, its gradient, direction, trial point, its gradient
+  double *J, *Jt, *alpha, *lam, *gtd, *fmax;  // [B]
+  double* hist;               // [memory][B] last objective values (non-monotone line search)
+  int *active, *accepted, *iters;  // [B]
+  int* counter;               // instances still active (which = 1) / rejected by the line search (which = 2)
+};
+// which: 0 init, 1 stopping test + direction + first trial, 2 Armijo test + next trial, 3 take the step, 4 verdict
+int launch_spg(int which, const SpgArgs& a, int it, double* pgnorm, int* converged, hipStream_t s);
 int control_grid_parts(int N);
 // batched vectorInterpolant: V [n][nComp][B] -> out [nq][nComp][B]; method as OCS_INTERP_*; t: tables of the sample grid
 int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* KQ, const double* SQ, int batch,

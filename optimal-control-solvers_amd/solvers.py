@@ -152,18 +152,22 @@ def compute_equilibrium(prob, xGuess, lamGuess, uGuess, lb, ub, r):
 
 
 def single_shooting_batch(prob, x0, tspan, nCONTROL_PTS, Control=None, Integrator=None, u0=0.0, TolX=1e-5,
-                          TolFun=3e-4, MaxIter=500, memory=10, verbose=False):
+                          TolFun=3e-4, MaxIter=500, memory=10, FreeInitStates=(), FreeStateBounds=None, v0=None):
     """Batched direct single shooting: B independent NLPs  min_v J_b(v), Lb <= v <= Ub  --
-    one per column of x0 and/or per per-trajectory parameter set of `prob` -- solved together on the GPU.
+    one per column of x0 and/or per per-trajectory parameter set of `prob` -- solved together on the GPU by the
+    library's ocs_single_shooting_batch_dev.
 
     The reference runs fmincon('sqp') on one problem at a time (single_shooting.m:114); fmincon is a MATLAB
-    toolbox, so the outer iteration here is a batched spectral projected gradient (Birgin-Martinez-Raydan SPG:
+    toolbox, so the outer iteration is a batched spectral projected gradient (Birgin-Martinez-Raydan SPG:
     Barzilai-Borwein step, projection on the bounds of compute_nlp_bounds, non-monotone Armijo back-tracking),
     every instance with its own step length and stopping test, every objective/gradient evaluation one call
-    of the hot path (nlp_objective_dev) over the whole batch.  Iterates differ from fmincon's; the optimum
+    of the hot path (nlpObjective) over the whole batch.  Iterates differ from fmincon's; the optimum
     is the same KKT point.  Stopping (per instance): ||P(v - g) - v||_inf <= TolFun or step <= TolX.
-    Returns a dict of device tensors: v [nV][B], J [B], iterations [B], converged [B] and the callables of
-    `soln_of(b)` (J, v and the control callable of instance b)."""
+    Free initial states ride at the tail of v, starting at x0 (single_shooting.m:81-85), inside FreeStateBounds
+    (nFree x 2, :91-94; default unbounded).
+    Returns a dict of device tensors: v [nV(+nFree)][B], J [B], iterations [B], converged [B],
+    projected_gradient [B], x0 [nS][B] and `soln_of(b)` (J, v and the control callable of instance b)."""
+    from ._lib import SsOptions
     tspan = _f(tspan).ravel()
     integrator = Integrator or RK4Integrator(tspan)
     nC = prob.ControlBounds.shape[0]
@@ -171,76 +175,48 @@ def single_shooting_batch(prob, x0, tspan, nCONTROL_PTS, Control=None, Integrato
     dev = torch.device("cuda", torch.cuda.current_device())
     x0 = np.asarray(x0, dtype=np.float64).reshape(prob.nS, -1)
     B = x0.shape[1]
-    x0d = torch.tensor(x0, device=dev)
-    u0c = np.minimum(prob.ControlBounds[:, 1], np.maximum(prob.ControlBounds[:, 0],
-                                                           np.broadcast_to(np.asarray(u0, dtype=np.float64).ravel(), (nC,))))
-    v0 = control.compute_initial_v(u0c)
-    nV = v0.size
+    x0d = torch.tensor(x0, device=dev).contiguous()
+    nFree, fis = _fis(FreeInitStates)
+    if v0 is None:
+        u0c = np.minimum(prob.ControlBounds[:, 1], np.maximum(prob.ControlBounds[:, 0],
+                                                               np.broadcast_to(np.asarray(u0, dtype=np.float64).ravel(), (nC,))))
+        v0 = np.repeat(control.compute_initial_v(u0c)[:, None], B, axis=1)
+    else:
+        v0 = np.asarray(v0, dtype=np.float64)
+        v0 = np.repeat(v0[:, None], B, axis=1) if v0.ndim == 1 else v0
+    nV = v0.shape[0]
     if hasattr(control, "compute_nlp_bounds"):
         Lb, Ub = control.compute_nlp_bounds(prob.ControlBounds)
     else:
         Lb, Ub = np.full(nV, -np.inf), np.full(nV, np.inf)
-    lb = torch.tensor(Lb, device=dev)[:, None]
-    ub = torch.tensor(Ub, device=dev)[:, None]
-    v = torch.tensor(np.repeat(v0[:, None], B, axis=1), device=dev).contiguous()
-    proj = lambda w: torch.minimum(torch.maximum(w, lb), ub)
-
-    def fg(w):
-        J, g = nlp_objective_dev(integrator, prob, control, x0d.clone(), w.contiguous())
-        return J, g
-
-    J, g = fg(v)
-    alpha = torch.full((B,), 1.0, dtype=torch.float64, device=dev)
-    pg = proj(v - g) - v
-    alpha = 1.0 / torch.clamp(pg.abs().amax(dim=0), min=1e-12)
-    hist = J[None, :].repeat(memory, 1)
-    active = torch.ones(B, dtype=torch.bool, device=dev)
-    iters = torch.zeros(B, dtype=torch.int32, device=dev)
-    gamma = 1e-4
-    for it in range(MaxIter):
-        pgn = (proj(v - g) - v).abs().amax(dim=0)
-        active = active & (pgn > TolFun)
-        if not bool(active.any()):
-            break
-        d = proj(v - alpha[None, :] * g) - v
-        gtd = (g * d).sum(dim=0)
-        fmax = hist.amax(dim=0)
-        lam = torch.ones(B, dtype=torch.float64, device=dev)
-        vnew, Jnew, gnew = v, J, g
-        accepted = ~active
-        for _ in range(25):
-            trial = torch.where(accepted[None, :], vnew, v + lam[None, :] * d)
-            Jt, gt = fg(trial)
-            ok = (~accepted) & (Jt <= fmax + gamma * lam * gtd)
-            vnew = torch.where(ok[None, :], trial, vnew)
-            Jnew = torch.where(ok, Jt, Jnew)
-            gnew = torch.where(ok[None, :], gt, gnew)
-            accepted = accepted | ok
-            if bool(accepted.all()):
-                break
-            lam = torch.where(accepted, lam, lam * 0.5)
-        stalled = ~accepted                      # line search failed: stop that instance where it is
-        s = vnew - v
-        yv = gnew - g
-        sty = (s * yv).sum(dim=0)
-        sts = (s * s).sum(dim=0)
-        alpha_new = torch.where(sty > 0, sts / torch.clamp(sty, min=1e-300), torch.full_like(sts, 1e3))
-        alpha = torch.where(active & accepted, torch.clamp(alpha_new, 1e-10, 1e10), alpha)
-        small = s.abs().amax(dim=0) <= TolX
-        iters = iters + active.to(torch.int32)
-        v, J, g = vnew, Jnew, gnew
-        hist[it % memory] = J
-        active = active & ~stalled & ~small
-        if verbose:
-            print(f"it {it}: active {int(active.sum())}, max projected gradient {float(pgn.max()):.3e}")
-    pgn = (proj(v - g) - v).abs().amax(dim=0)
-    out = {"v": v, "J": J, "iterations": iters, "converged": pgn <= 10 * TolFun, "projected_gradient": pgn,
+    if nFree:                                                             # :84: v0 = [v0; x0(FreeInitStates)]
+        idx = [int(i) - 1 for i in np.asarray(FreeInitStates).ravel()]
+        v0 = np.vstack([v0, x0[idx, :]])
+        fsb = (np.tile([-np.inf, np.inf], (nFree, 1)) if FreeStateBounds is None
+               else np.asarray(FreeStateBounds, dtype=np.float64).reshape(nFree, 2))
+        Lb = np.concatenate([Lb, fsb[:, 0]])                              # :91-94
+        Ub = np.concatenate([Ub, fsb[:, 1]])
+    Lb, Ub = _f(Lb).ravel().copy(), _f(Ub).ravel().copy()
+    v = torch.tensor(np.ascontiguousarray(v0), device=dev).contiguous()
+    J = torch.empty(B, dtype=torch.float64, device=dev)
+    pgn = torch.empty(B, dtype=torch.float64, device=dev)
+    iters = torch.empty(B, dtype=torch.int32, device=dev)
+    conv = torch.empty(B, dtype=torch.int32, device=dev)
+    o = SsOptions()
+    check(lib.ocs_ss_default_options(C.byref(o)))
+    o.TolX, o.TolFun, o.MaxIter, o.memory = float(TolX), float(TolFun), int(MaxIter), int(memory)
+    rc = lib.ocs_single_shooting_batch_dev(integrator._h, prob._h, control._h, B, _dptr(x0d), _dptr(v), nFree, fis,
+                                           _p(Lb), _p(Ub), C.byref(o), _dptr(J), C.c_void_p(iters.data_ptr()), C.c_void_p(conv.data_ptr()), _dptr(pgn),
+                                           _stream())
+    if rc < 0:
+        check(rc)
+    out = {"v": v, "J": J, "iterations": iters, "converged": conv.to(torch.bool), "projected_gradient": pgn, "x0": x0d,
            "control": control, "integrator": integrator}
 
     def soln_of(b):
         """J, the coefficient vector and soln.u (compute_uFunc) of instance b."""
         vb = v[:, b].cpu().numpy()
-        return {"J": float(J[b]), "v": vb, "u": control.compute_uFunc(vb)}
+        return {"J": float(J[b]), "v": vb, "u": control.compute_uFunc(vb[:vb.size - nFree])}
 
     out["soln_of"] = soln_of
     return out

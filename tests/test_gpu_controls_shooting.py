@@ -212,6 +212,36 @@ def test_single_shooting_batch_on_device(ocs, oracle):
         assert np.max(np.abs(s["v"] - res.x)) < 5e-3
 
 
+def test_single_shooting_batch_free_initial_states(ocs, oracle):
+    """The batched driver with FreeInitStates inside FreeStateBounds (single_shooting.m:81-94, :144-149): each
+    instance against SLSQP on the oracle's nlpObjective with the same bounds.  (The free state ends on its lower
+    bound, the control coefficients partly inside their bounds.)"""
+    from scipy.optimize import minimize
+    rng = np.random.default_rng(3)
+    B, N, nPts = 10, 100, 11
+    tspan = oracle.linspace(0, 5, N + 1)
+    x0 = rng.uniform(0.95, 1.5, (1, B))
+    cs = rng.uniform(1.0, 2.0, B)
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    fsb = [[0.9, 2.0]]
+    r = ocs.single_shooting_batch(prob, x0, tspan, nPts, u0=0.3, TolFun=1e-7, TolX=1e-12, MaxIter=600,
+                                  FreeInitStates=[1], FreeStateBounds=fsb)
+    assert bool(r["converged"].all()) and int(r["iterations"].max()) < 200
+    J, V, x0n = r["J"].cpu().numpy(), r["v"].cpu().numpy(), r["x0"].cpu().numpy()
+    assert np.array_equal(x0n[0], V[nPts])                                           # :121-124
+    assert np.all(V[nPts] >= 0.9) and np.all(V[nPts] <= 2.0) and np.all(V[:nPts] >= 0) and np.all(V[:nPts] <= 1)
+    go = oracle.RK4Integrator(tspan)
+    co = oracle.PWLinearControl(go.t, nPts, 1)
+    for b in (0, 4, 9):
+        po = oracle.TestOCProblem({"c": cs[b], "m": P["m"], "r": P["r"]}, BOUNDS)
+        f = lambda v: oracle.nlp_objective(go, po, co, x0[:, b], v, FreeInitStates=[1])[:2]
+        res = minimize(f, np.concatenate([np.full(nPts, 0.3), [x0[0, b]]]), jac=True, method="SLSQP",
+                       bounds=[(0.0, 1.0)] * nPts + [tuple(fsb[0])], options={"ftol": 1e-13, "maxiter": 500})
+        assert abs(J[b] - res.fun) < 2e-6 * abs(res.fun)
+        assert np.max(np.abs(V[:, b] - res.x)) < 5e-3
+
+
 def test_dense_basis_kernels_large_batch(ocs, oracle):
     # Chebyshev is a dense basis: at batch >= 16384 the register-resident kernels take over
     import torch

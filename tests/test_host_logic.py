@@ -109,3 +109,6 @@ def test_registry_and_option_validation_without_gpu(ocs):
     o = _lib.FbsOptions()
     assert _lib.lib.ocs_fbs_default_options(C.byref(o)) == 0
     assert (o.uRelTol, o.uAbsTol, o.nSWEEPS, o.nERROR_PTS, o.nINTERP_PTS, o.fused_update_off) == (1e-7, 1e-7, 50, 1001, 1001, 0)
+    so = _lib.SsOptions()                       # single_shooting.m:20-21 defaults of the batched shooting driver
+    assert _lib.lib.ocs_ss_default_options(C.byref(so)) == 0 and _lib.lib.ocs_ss_default_options(None) == -1
+    assert (so.TolX, so.TolFun, so.MaxIter, so.memory, so.maxBacktracks) == (1e-5, 3e-4, 500, 10, 25)
