@@ -148,21 +148,6 @@ struct LogisticK {
     const double v = s * tu[0] / (2.0 * p.c);
     u[0] = fmin(ub[0], fmax(lb[0], v));
   }
-  // the same with the per-trajectory constant 1/(2c) formed once (kernels that evaluate ControlChar at every grid
-  // point of a sweep; differs from control_char by the rounding of one reciprocal)
-  struct CCPre {
-    double inv2c;
-  };
-  __device__ static inline CCPre cc_prepare(const Par& p) { return CCPre{1.0 / (2.0 * p.c)}; }
-  __device__ static inline void control_char_pre(const double* tu, const double* x, const double* lam, const Par& p,
-                                                 const CCPre& q, const double* lb, const double* ub, double* u) {
-    (void)x;
-    (void)p;
-    double s = lam[0];
-#pragma unroll
-    for (int k = 1; k < NS; ++k) s += lam[k];
-    u[0] = fmin(ub[0], fmax(lb[0], s * tu[0] * q.inv2c));
-  }
 };
 
 }  // namespace ocs
