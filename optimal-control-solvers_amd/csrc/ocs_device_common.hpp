@@ -65,6 +65,18 @@ __device__ static inline StepRec<NTC> load_rec(const double* q) {
   return r;
 }
 
+// pchip (Fritsch-Carlson / MATLAB pchipslopes) interior slope of a node between secants del0, del1 with weights w1, w2:
+// with ONE division: |del0 del1| / (w1 |del0| + w2 |del1|) (pchip_interior's harmonic mean multiplied
+// through by dmax; round-off level difference to the two-division form of the midpoint kernel)
+__device__ static inline double pchip_interior1(double del0, double del1, double w1, double w2) {
+  const bool same = (del0 > 0.0 && del1 > 0.0) || (del0 < 0.0 && del1 < 0.0);
+  const double a0 = fabs(del0), a1 = fabs(del1);
+  double d = (a0 * a1) / __builtin_fma(w1, a0, w2 * a1);
+  asm("" : "+v"(d));  // opaque: keeps the division out of a divergent branch (0/0 lanes are discarded below); not
+                      // volatile, so that the divisions of neighbouring nodes still overlap
+  return same ? (del0 > 0.0 ? d : -d) : 0.0;
+}
+
 // The record table is written by another kernel and is cold in this XCD's L2: a scalar load
 // that misses to the Infinity Cache / HBM costs more than a whole RK4 step.  Every wave
 // therefore sweeps the table once with wide vector loads (1 KiB per instruction) before the

@@ -111,7 +111,7 @@ __device__ static inline void pchip_run_w(const PchipTab& T, const double (&w)[R
     else if (k == n - 1)
       dk = pchip_end(T.HN[n - 2], T.HN[n - 3], sec[c + 1], sec[c]);
     else if (k < n - 1)
-      dk = pchip_interior2(sec[c + 1], sec[c + 2], T.W1[k], T.W2[k]);
+      dk = pchip_interior1(sec[c + 1], sec[c + 2], T.W1[k], T.W2[k]);
     else
       dk = 0.0;
     d[c] = dk;
@@ -389,7 +389,9 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) pchip_mid_run<R>(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i0, a.TM, xmr[k]);
   }
-  double wmax = 0.0;
+  // the largest weighted change as a fraction nmax / dmax: ratios are compared by cross-multiplication and divided
+  // once per thread (fp64 divisions were a large share of this kernel's instructions)
+  double nmax = 0.0, dmax = 1.0;
   bool any = false;
   auto emit = [&](int j, const double* x, const double* lam) OCS_INLINE {  // grid point j
     double tu[NTU], u[NC];
@@ -401,9 +403,12 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
       double* dst = a.u + ((size_t)j * NC + c) * B + b;
       if (a.metric && !(j & 1)) {  // a node: max() skips NaN (:108)
         const double o = *dst;
-        const double w = fabs(u[c] - o) / (a.relTol * fabs(o) + a.absTol);
-        if (w == w) {
-          wmax = any ? fmax(wmax, w) : w;
+        const double n = fabs(u[c] - o), d = a.relTol * fabs(o) + a.absTol;
+        if (n == n && d == d && !(n == 0.0 && d == 0.0)) {  // n / d is not NaN
+          if (!any || n * dmax > nmax * d) {
+            nmax = n;
+            dmax = d;
+          }
           any = true;
         }
       }
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
     }
     emit(2 * N, x, lam);
   }
-  if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? wmax : -1.0;
+  if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? nmax / dmax : -1.0;
 }
 
 // ---------------------------------------------------------------------------------------

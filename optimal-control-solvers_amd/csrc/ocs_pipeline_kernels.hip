@@ -756,15 +756,6 @@ struct CostateXArgs {
   const double* PR;    // [N][kPRec]
 };
 
-// interior slope with ONE division: |del0 del1| / (w1 |del0| + w2 |del1|) (pchip_interior's harmonic mean multiplied
-// through by dmax; round-off level difference to the two-division form of the midpoint kernel)
-__device__ static inline double pchip_interior1(double del0, double del1, double w1, double w2) {
-  const bool same = (del0 > 0.0 && del1 > 0.0) || (del0 < 0.0 && del1 < 0.0);
-  const double a0 = fabs(del0), a1 = fabs(del1);
-  double d = (a0 * a1) / __builtin_fma(w1, a0, w2 * a1);
-  asm volatile("" : "+v"(d));  // keep the division out of a divergent branch (0/0 lanes are discarded below)
-  return same ? (del0 > 0.0 ? d : -d) : 0.0;
-}
 __device__ static inline double pchip_end_pl(double h0, double h1, double del0, double del1) {
   double d = ((2.0 * h0 + h1) * del0 - h0 * del1) / (h0 + h1);
   const bool s0 = (d > 0.0) == (del0 > 0.0) && (d < 0.0) == (del0 < 0.0);
