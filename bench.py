@@ -12,7 +12,8 @@ batch * N fused RK4 state+costate steps.  Inputs are synthetic and already resid
          --master-port P bench.py --gpus N --steps K --warmup W
 
 Multi-GPU: the batch axis shards with no data-path exchange (weak scaling, 4096 per GPU); the
-only collective is the all-reduce(SUM) of the objective sum over ranks (north_star), 8 bytes.
+only collective is the all-reduce(SUM) of the objective sum over ranks (north_star), 8 bytes per step,
+issued asynchronously so that it overlaps the next step's kernels.
 """
 import argparse
 import json
@@ -225,11 +226,13 @@ def main():
     lam = torch.empty_like(x)
     dJdu = torch.empty_like(u)
     J = torch.empty(batch, dtype=torch.float64, device=dev)
-    Jsum = torch.zeros(1, dtype=torch.float64, device=dev)
+    # one 8-byte buffer per step of a phase: the objective all-reduce of step k overlaps the kernels of step k+1
+    Jsums = torch.zeros((max(args.steps, args.warmup, 1), 1), dtype=torch.float64, device=dev)
+    pending = []
 
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(args.steps)]
 
-    def one_step(k=None):
+    def one_step(i, k=None):
         if k is not None:
             ev[k][0].record()
         integ.compute_states_dev(prob, x0, u, x, J)
@@ -238,16 +241,25 @@ def main():
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
         if k is not None:
             ev[k][2].record()
-        if world > 1:  # the one collective of the path: all-reduce(SUM) of the objective over the shards
-            torch.sum(J, dim=0, keepdim=True, out=Jsum)
-            dist.all_reduce(Jsum)
+        if world > 1:
+            # the one collective of the path: all-reduce(SUM) of the objective over the shards, 8 bytes; issued
+            # asynchronously on RCCL's stream so that its latency hides under the next step's kernels
+            torch.sum(J, dim=0, keepdim=True, out=Jsums[i])
+            pending.append(dist.all_reduce(Jsums[i], async_op=True))
 
-    for _ in range(args.warmup):
-        one_step()
+    def drain():
+        for w in pending:
+            w.wait()
+        pending.clear()
+
+    for i in range(args.warmup):
+        one_step(i)
+    drain()
     torch.cuda.synchronize()
     # per-kernel durations (roofline): K untimed steps with HIP events between the two kernels
     for k in range(args.steps):
-        one_step(k)
+        one_step(k, k)
+    drain()
     torch.cuda.synchronize()
     # (HIP event records between the kernels cost a few us of GPU idle time each, so the timed steps below carry none;
     #  replaying the two kernels from a captured graph was measured slower than plain stream launches: 222 vs 209 us)
@@ -256,7 +268,8 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        one_step()
+        one_step(k)
+    drain()  # every step's objective sum has arrived before the clock stops
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
