@@ -134,7 +134,11 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
   using C_ = PLCfg<G, false>;
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
-  __shared__ __attribute__((aligned(16))) double stage[2][4][D][64];    // [buffer][Y1..Y4][step][lane]
+  // [buffer][Y1..Y4][step][lane], the step stride padded so that the objective wave, whose lanes of a trajectory
+  // take consecutive steps, reads G rows of a step per lane without bank conflicts
+  constexpr int SS = (G == 1) ? 64 : 72;
+  __shared__ __attribute__((aligned(16))) double stage[2][4][D][SS];
+  __shared__ double ulast[2][64];  // control sample at the first node of a block (S -> C)
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];  // [slot]{records | u}
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -179,7 +183,9 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
     }
 #endif
     (void)tw; (void)tb; (void)t00;
-  } else {
+  } else if (G == 1) {
+    // One row per trajectory: nothing to reduce across lanes and no redundant store, so S keeps the plain recursion
+    // with its own stores and C sums the objective lane by lane.
     const int r = lane % G;
     const int tl = lane / G;
     const int b = bw + tl;
@@ -196,10 +202,13 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
     const double u0 = a.u[b];
     if (wave == 1) {
       // ---------------- S: state recursion ----------------
-      double y = a.x0[(size_t)r * B + b];
-      double uprev = u0;
+      // the recursion runs on z = y - m_r/2 (P::row_f_shifted: two dependent operations per stage, not three)
+      const double mh = P::row_shift(rp);
+      const double y0 = a.x0[(size_t)r * B + b];
+      double y = y0 - mh;
+      double cprev = P::row_vertex(mh, u0);
       double* xs = a.x + (size_t)r * B + b;
-      if (OUT_X && !fz) *xs = y;
+      if (OUT_X && !fz) *xs = y0;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
         const long long t0 = PL_T();
@@ -228,23 +237,24 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             const In c = nxt;
             if (s + 1 < D) nxt = fetch(s + 1);
             __builtin_amdgcn_sched_barrier(0);
-            w[s * 64] = y;                                 // Y1 = y_i
-            const double F1 = P::row_f(y, uprev, rp);
+            const double cM = P::row_vertex(mh, c.uM), cB = P::row_vertex(mh, c.uB);
+            w[s * SS] = y;                                 // Y1 - m/2
+            const double F1 = P::row_f_shifted(y, cprev);
             double Y = __builtin_fma(c.hh, F1, y);
-            w[(D + s) * 64] = Y;                           // Y2
-            const double F2 = P::row_f(Y, c.uM, rp);
+            w[(D + s) * SS] = Y;                           // Y2 - m/2
+            const double F2 = P::row_f_shifted(Y, cM);
             Y = __builtin_fma(c.hh, F2, y);
-            w[(2 * D + s) * 64] = Y;                       // Y3
-            const double F3 = P::row_f(Y, c.uM, rp);
+            w[(2 * D + s) * SS] = Y;                       // Y3 - m/2
+            const double F3 = P::row_f_shifted(Y, cM);
             Y = __builtin_fma(c.h, F3, y);
-            w[(3 * D + s) * 64] = Y;                       // Y4
-            const double F4 = P::row_f(Y, c.uB, rp);
+            w[(3 * D + s) * SS] = Y;                       // Y4 - m/2
+            const double F4 = P::row_f_shifted(Y, cB);
             y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
             if (OUT_X) {
               xs += colB;
-              if (!fz) *xs = y;
+              if (!fz) *xs = y + mh;
             }
-            uprev = c.uB;
+            cprev = cB;
           }
         }
         tc += PL_T() - t1;
@@ -260,6 +270,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       // ---------------- C: objective ----------------
       // pc += W_A q1 + W_M (q2 + q3) + W_B q4 with the quadrature weights of the record table
       // (W_A = h/6 e^{-r t_A}, ...): the same sum as h/6 (F1 + 2 F2 + 2 F3 + F4) of the cost row.
+      const double mh = P::row_shift(rp);  // the stage values arrive as Y - m_r/2
       double pc = 0.0, uprev2 = u0 * u0;
       double* xc = a.x + (size_t)G * B + b;
       if (OUT_X && !fz) *xc = 0.0;
@@ -282,10 +293,10 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             v.wB = rec[RS * s + SCO + 5];
             v.uM = us[(2 * s) * TPW];
             v.uB = us[(2 * s + 1) * TPW];
-            v.Y1 = w[s * 64];
-            v.Y2 = w[(D + s) * 64];
-            v.Y3 = w[(2 * D + s) * 64];
-            v.Y4 = w[(3 * D + s) * 64];
+            v.Y1 = w[s * SS];
+            v.Y2 = w[(D + s) * SS];
+            v.Y3 = w[(2 * D + s) * SS];
+            v.Y4 = w[(3 * D + s) * SS];
             return v;
           };
           In nxt = fetch(0);
@@ -295,8 +306,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             if (s + 1 < D) nxt = fetch(s + 1);
             __builtin_amdgcn_sched_barrier(0);
             const double uM2 = c.uM * c.uM, uB2 = c.uB * c.uB;
-            const double q1 = P::row_q(c.Y1, uprev2, rp), q2 = P::row_q(c.Y2, uM2, rp);
-            const double q3 = P::row_q(c.Y3, uM2, rp), q4 = P::row_q(c.Y4, uB2, rp);
+            const double q1 = P::row_q(c.Y1 + mh, uprev2, rp), q2 = P::row_q(c.Y2 + mh, uM2, rp);
+            const double q3 = P::row_q(c.Y3 + mh, uM2, rp), q4 = P::row_q(c.Y4 + mh, uB2, rp);
             pc = __builtin_fma(c.wA, q1, __builtin_fma(c.wM, q2 + q3, __builtin_fma(c.wB, q4, pc)));
             if (OUT_X) {
               xc += colB;
@@ -318,6 +329,186 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       const double Jt = group_sum_pl<G>(pc);
       if (!fz) a.J[b] = Jt;
     }
+  } else if (wave == 1) {
+    // ---------------- S: state recursion ----------------
+    // Only the recursion: the stage states go to LDS, C stores the trajectory from there.  The recursion runs on
+    // z = y - m_r/2 (P::row_f_shifted: two dependent operations per stage instead of three).
+    const int r = lane % G;
+    const int tl = lane / G;
+    const int b = bw + tl;
+    const uniform_ptr PS = as_uniform(a.ps);
+    const typename P::RowPar rp = P::load_row([&](int k) OCS_INLINE {
+      return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+    }, r);
+    const bool fz = FRZ && a.frozen[b] != 0;
+    const double mh = P::row_shift(rp);
+    double uprev = a.u[b];
+    double y = a.x0[(size_t)r * B + b] - mh;
+    double cprev = P::row_vertex(mh, uprev);
+    long long tb = 0, tc = 0;
+    for (int k = 0; k <= nb; ++k) {
+      const long long t0 = PL_T();
+      lds_barrier();
+      const long long t1 = PL_T();
+      tb += t1 - t0;
+      if (k < nb) {
+        const double* rec = &inp[k % NSLOT][0];
+        const double* us = rec + C_::REC_DBL + tl;
+        double* w = &stage[k & 1][0][0][lane];
+        ulast[k & 1][lane] = uprev;
+        // LDS reads of step s+1 are issued before step s is computed (LDS latency ~100 cycles would
+        // otherwise sit on every step: the scheduler keeps loads next to their uses)
+        struct In { double h, hh, h6, uM, uB; };
+        auto fetch = [&](int s) OCS_INLINE {
+          In v;
+          v.h = rec[RS * s];
+          v.hh = rec[RS * s + 1];
+          v.h6 = rec[RS * s + 2];
+          v.uM = us[(2 * s) * TPW];
+          v.uB = us[(2 * s + 1) * TPW];
+          return v;
+        };
+        In nxt = fetch(0);
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          const In c = nxt;
+          if (s + 1 < D) nxt = fetch(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const double cM = P::row_vertex(mh, c.uM), cB = P::row_vertex(mh, c.uB);
+          w[s * SS] = y;                                 // Y1 - m/2
+          const double F1 = P::row_f_shifted(y, cprev);
+          double Y = __builtin_fma(c.hh, F1, y);
+          w[(D + s) * SS] = Y;                           // Y2 - m/2
+          const double F2 = P::row_f_shifted(Y, cM);
+          Y = __builtin_fma(c.hh, F2, y);
+          w[(2 * D + s) * SS] = Y;                       // Y3 - m/2
+          const double F3 = P::row_f_shifted(Y, cM);
+          Y = __builtin_fma(c.h, F3, y);
+          w[(3 * D + s) * SS] = Y;                       // Y4 - m/2
+          const double F4 = P::row_f_shifted(Y, cB);
+          y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
+          cprev = cB;
+          uprev = c.uB;
+        }
+      }
+      tc += PL_T() - t1;
+    }
+#ifdef OCS_PL_STAMPS
+    if (a.dbg && lane == 0) {
+      a.dbg[blockIdx.x * 16 + 4] = tb;
+      a.dbg[blockIdx.x * 16 + 5] = tc;
+    }
+#endif
+    (void)tb; (void)tc;
+    if (OUT_X && !fz) a.x[((size_t)a.N * NAUG + r) * B + b] = y + mh;  // x(t_N); the other nodes are stored by C
+  } else {
+    // ---------------- C: objective and the stores of the trajectory ----------------
+    // The G lanes of a trajectory take G consecutive steps (not the G rows of one step): a lane reads all rows of its
+    // step, so the sum over the rows needs no cross-lane reduction, the running objective is a prefix sum over the
+    // lanes of a quad, and every value is stored once.
+    //   d_i = W_A q1 + W_M (q2 + q3) + W_B q4,  q_j = sum_r row_q(Y_j,r), with the quadrature weights of the record
+    //   table (W_A = h/6 e^{-r t_A}, ...): the same sum as h/6 (F1 + 2 F2 + 2 F3 + F4) of the cost row.
+    const int csub = lane % G;
+    const int ctl = lane / G;
+    const int b = bw + ctl;
+    const uniform_ptr PS = as_uniform(a.ps);
+    typename P::RowPar rpr[G];
+    double mhr[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      rpr[q] = P::load_row([&](int k) OCS_INLINE {
+        return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+      }, q);
+      mhr[q] = P::row_shift(rpr[q]);
+    }
+    const bool fz = FRZ && a.frozen[b] != 0;
+    const size_t colB = (size_t)NAUG * B;
+    double carry = 0.0;  // running objective at the node before this lane's step (OUT_X) / this lane's share (else)
+    if (OUT_X && !fz && csub == 0) a.x[(size_t)G * B + b] = 0.0;
+    long long tb = 0, tc = 0;
+    for (int k = 0; k <= nb; ++k) {
+      const long long t0 = PL_T();
+      lds_barrier();
+      const long long t1 = PL_T();
+      tb += t1 - t0;
+      if (k >= 1) {
+        const int j = k - 1;
+        const double* rec = &inp[j % NSLOT][0];
+        const double* us = rec + C_::REC_DBL + ctl;
+        const double* st = &stage[j & 1][0][0][ctl * G];
+        const double ublk = ulast[j & 1][ctl * G];
+        // all LDS reads of the block first (the passes below then wait for their own only)
+        struct In { double wA, wM, wB, uA, uM, uB, Y[4][G]; };
+        In in[D / G];
+#pragma unroll
+        for (int p0 = 0; p0 < D; p0 += G) {
+          const int s = p0 + csub;
+          In& v = in[p0 / G];
+          v.wA = rec[RS * s + SCO + 3];
+          v.wM = rec[RS * s + SCO + 4];
+          v.wB = rec[RS * s + SCO + 5];
+          v.uM = us[(2 * s) * TPW];
+          v.uB = us[(2 * s + 1) * TPW];
+          v.uA = us[(s > 0 ? 2 * s - 1 : 0) * TPW];
+#pragma unroll
+          for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+            for (int q = 0; q < G; ++q) v.Y[jj][q] = st[(jj * D + s) * SS + q];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p0 = 0; p0 < D; p0 += G) {
+          const int s = p0 + csub;
+          const In& c = in[p0 / G];
+          const double uA = s > 0 ? c.uA : ublk;
+          const double uA2 = uA * uA, uM2 = c.uM * c.uM, uB2 = c.uB * c.uB;
+          double Y1[G];
+          const double cqM = P::control_q(uM2, rpr[0]);
+          double q1 = P::control_q(uA2, rpr[0]), q2 = cqM, q3 = cqM, q4 = P::control_q(uB2, rpr[0]);
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            Y1[q] = c.Y[0][q] + mhr[q];
+            q1 = P::state_q_acc(Y1[q], q1);
+            q2 = P::state_q_acc(c.Y[1][q] + mhr[q], q2);
+            q3 = P::state_q_acc(c.Y[2][q] + mhr[q], q3);
+            q4 = P::state_q_acc(c.Y[3][q] + mhr[q], q4);
+          }
+          const double d = __builtin_fma(c.wA, q1, __builtin_fma(c.wM, q2 + q3, c.wB * q4));
+          if (OUT_X) {
+            // inclusive prefix over the G steps of the pass, on top of the running objective
+            double pre = d;
+            if (G >= 2) {
+              const double t = dpp_quad_pl<(G == 4) ? 0x90 : 0xA0>(pre);  // lane <- lane - 1
+              pre += (csub >= 1) ? t : 0.0;
+            }
+            if (G == 4) {
+              const double t = dpp_quad_pl<0x44>(pre);                    // lane <- lane - 2
+              pre += (csub >= 2) ? t : 0.0;
+            }
+            const double tot = carry + pre;
+            if (!fz) {
+              double* xn = a.x + (size_t)(j * D + s) * colB + b;  // node i = j D + s
+#pragma unroll
+              for (int q = 0; q < G; ++q) xn[(size_t)q * B] = Y1[q];
+              xn[colB + (size_t)G * B] = tot;                      // objective at node i + 1
+            }
+            carry = (G == 1) ? tot : dpp_quad_pl<(G == 4) ? 0xFF : 0xF5>(tot);  // the pass's last lane
+          } else {
+            carry += d;
+          }
+        }
+      }
+      tc += PL_T() - t1;
+    }
+#ifdef OCS_PL_STAMPS
+    if (a.dbg && lane == 0) {
+      a.dbg[blockIdx.x * 16 + 8] = tb;
+      a.dbg[blockIdx.x * 16 + 9] = tc;
+    }
+#endif
+    (void)tb; (void)tc;
+    const double Jt = OUT_X ? carry : group_sum_pl<G>(carry);
+    if (!fz) a.J[b] = Jt;
   }
 }
 

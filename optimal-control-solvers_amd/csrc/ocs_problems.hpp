@@ -118,10 +118,20 @@ struct LogisticK {
   __device__ static inline double row_f(double y, double u, const RowPar& rp) {
     return __builtin_fma(y, rp.m - y, -u);
   }
+  // The same row about its vertex: with z = y - m_r/2,  F_r = (m_r^2/4 - u) - z^2, and y + a F becomes z + a F.
+  // A marching wave that carries z instead of y has two dependent operations per RK4 stage instead of three
+  // (the constant m_r^2/4 - u does not depend on the state); results differ from row_f by round-off only.
+  __device__ static inline double row_shift(const RowPar& rp) { return 0.5 * rp.m; }
+  __device__ static inline double row_vertex(double mh, double u) { return __builtin_fma(mh, mh, -u); }
+  __device__ static inline double row_f_shifted(double z, double cv) { return __builtin_fma(-z, z, cv); }
   // this row's share of the objective integrand, without the e^{-rt} factor:  y^2 + cw u^2
   __device__ static inline double row_q(double y, double u2, const RowPar& rp) {
     return __builtin_fma(rp.cw, u2, y * y);
   }
+  // the same integrand for a lane that holds all rows of one stage state: control_q(u^2) + sum_r state_q(y_r)
+  // (equal to sum_r row_q(y_r, u^2, rp_r): the control cost is charged to row 0 only)
+  __device__ static inline double control_q(double u2, const RowPar& rp0) { return rp0.cw * u2; }
+  __device__ static inline double state_q_acc(double y, double acc) { return __builtin_fma(y, y, acc); }
   // row r of (dF/dy)' v:  (m_r - 2 y) v_r + ev y,   ev = 2 e^{-rt} v_cost
   __device__ static inline double row_dfdx(double y, double v, double ev, const RowPar& rp) {
     return __builtin_fma(__builtin_fma(-2.0, y, rp.m), v, ev * y);

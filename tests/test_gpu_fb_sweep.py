@@ -154,11 +154,12 @@ def test_fused_costate_update_equals_separate_kernels(ocs, oracle, nS, N, batch)
         # result does not depend on which window it is in
         rw = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, nWINDOWS=2))
         assert np.array_equal(ra["sweeps"], rw["sweeps"])
-        for key in ("x", "lam", "u"):
-            assert np.array_equal(ra[key], rw[key]), key
-        # (J: a ragged last window runs the lane kernel, which sums the running objective in another order)
-        assert relerr(ra["J"], rw["J"]) < 1e-13
-        assert np.array_equal(np.nan_to_num(ra["maxChange"]), np.nan_to_num(rw["maxChange"]))
+        # (a ragged last window runs the lane kernel: another order of the objective sum, and the plain form of the
+        # logistic rows where the pipeline kernel marches about their vertex -- round-off level differences)
+        for key in ("x", "lam", "u", "J"):
+            assert relerr(ra[key], rw[key]) < 1e-12, key
+        assert relerr(np.nan_to_num(ra["maxChange"]), np.nan_to_num(rw["maxChange"])) < 1e-6
+        assert np.array_equal(np.isnan(ra["maxChange"]), np.isnan(rw["maxChange"]))
     # ... and with the pchip midpoints of x from their own kernel instead of inside the costate / control kernels
     rc = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=2))
     assert np.array_equal(ra["sweeps"], rc["sweeps"])
