@@ -538,7 +538,8 @@ struct BwdArgsPL {
                         // another kernel (a pass split at a multiple of the block length); default 0
 };
 
-template <class P, bool OUT_LAM, bool OUT_DJDU>
+// LT: a terminal costate was given; without one the cost row of lam is exactly 1 and the products with it drop out
+template <class P, bool OUT_LAM, bool OUT_DJDU, bool LT>
 __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   constexpr int G = P::NS, NAUG = P::NAUG;
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
@@ -695,17 +696,20 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
           const In c = nxt;
           if (s + 1 < D) nxt = fetch(s + 1);
           __builtin_amdgcn_sched_barrier(0);
-          const double ev4 = c.e4 * lamc, ev3 = c.e3 * lamc, ev1 = c.e1 * lamc;
+          const double ev4 = LT ? c.e4 * lamc : c.e4, ev3 = LT ? c.e3 * lamc : c.e3, ev1 = LT ? c.e1 * lamc : c.e1;
           const double h6l = c.h6 * lam, h3l = c.h3 * lam;
           const double k4 = h6l;                                   // :73
           const double g3 = P::row_dfdx(c.Y4, k4, ev4, rp);        // :74-75
-          const double k3 = __builtin_fma(c.h, g3, h3l);           // :77
+          double acc = lam + g3;                                   // :86-88, each term as soon as it exists: only
+          const double k3 = __builtin_fma(c.h, g3, h3l);           // :77     the last add stays on the dependent chain
           const double g2 = P::row_dfdx(c.Y3, k3, ev3, rp);        // :78-79
+          acc += g2;
           const double k2 = __builtin_fma(c.hh, g2, h3l);          // :81
           const double g1 = P::row_dfdx(c.Y2, k2, ev3, rp);        // :82-83
+          acc += g1;
           const double k1 = __builtin_fma(c.hh, g1, h6l);          // :85
           const double g0 = P::row_dfdx(c.Y1, k1, ev1, rp);        // :87-88
-          lam = (((lam + g1) + g2) + g3) + g0;                     // :86-88
+          lam = acc + g0;
           if (OUT_DJDU) {
             kw[(0 * D + s) * 64] = k1;
             kw[(1 * D + s) * 64] = k2 + k3;
@@ -766,7 +770,7 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
           const In c = nxt;
           if (s + 1 < D) nxt = fetch(s + 1);
           __builtin_amdgcn_sched_barrier(0);
-          const double ev4 = c.e4 * lamc, ev3 = c.e3 * lamc, ev1 = c.e1 * lamc;
+          const double ev4 = LT ? c.e4 * lamc : c.e4, ev3 = LT ? c.e3 * lamc : c.e3, ev1 = LT ? c.e1 * lamc : c.e1;
           const double cuA = rp.cw * c.uA, cuM = rp.cw * c.uM;
           const double p4 = P::row_dfdu(cunext, c.k4, ev4), p1 = P::row_dfdu(cuA, c.k1, ev1);
           // p2 + p3 = (cuM ev3 - k2) + (cuM ev3 - k3) = 2 cuM ev3 - (k2 + k3)
@@ -1241,12 +1245,20 @@ template <class P>
 static void run_backward_pl(const BwdArgsPL& a, hipStream_t s) {
   constexpr int TPW = 64 / P::NS;
   const dim3 grid(a.batch / TPW), block(256);
-  if (a.lam && a.dJdu)
-    k_backward_pl<P, true, true><<<grid, block, 0, s>>>(a);
-  else if (a.lam)
-    k_backward_pl<P, true, false><<<grid, block, 0, s>>>(a);
-  else
-    k_backward_pl<P, false, true><<<grid, block, 0, s>>>(a);
+  if (a.lamT) {
+    if (a.lam && a.dJdu)
+      k_backward_pl<P, true, true, true><<<grid, block, 0, s>>>(a);
+    else if (a.lam)
+      k_backward_pl<P, true, false, true><<<grid, block, 0, s>>>(a);
+    else
+      k_backward_pl<P, false, true, true><<<grid, block, 0, s>>>(a);
+  } else if (a.lam && a.dJdu) {
+    k_backward_pl<P, true, true, false><<<grid, block, 0, s>>>(a);
+  } else if (a.lam) {
+    k_backward_pl<P, true, false, false><<<grid, block, 0, s>>>(a);
+  } else {
+    k_backward_pl<P, false, true, false><<<grid, block, 0, s>>>(a);
+  }
 }
 int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                        const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
