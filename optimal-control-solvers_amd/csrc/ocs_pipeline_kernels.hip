@@ -184,8 +184,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
 #endif
     (void)tw; (void)tb; (void)t00;
   } else if (G == 1) {
-    // One row per trajectory: nothing to reduce across lanes and no redundant store, so S keeps the plain recursion
-    // with its own stores and C sums the objective lane by lane.
+    // One row per trajectory: nothing to reduce across lanes and no redundant store; C sums the objective lane by
+    // lane and, having slack, also stores the state row (from Y1), so that S only marches.
     const int r = lane % G;
     const int tl = lane / G;
     const int b = bw + tl;
@@ -207,8 +207,6 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       const double y0 = a.x0[(size_t)r * B + b];
       double y = y0 - mh;
       double cprev = P::row_vertex(mh, u0);
-      double* xs = a.x + (size_t)r * B + b;
-      if (OUT_X && !fz) *xs = y0;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
         const long long t0 = PL_T();
@@ -250,10 +248,6 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             w[(3 * D + s) * SS] = Y;                       // Y4 - m/2
             const double F4 = P::row_f_shifted(Y, cB);
             y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
-            if (OUT_X) {
-              xs += colB;
-              if (!fz) *xs = y + mh;
-            }
             cprev = cB;
           }
         }
@@ -266,6 +260,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       }
 #endif
       (void)tb; (void)tc;
+      if (OUT_X && !fz) a.x[((size_t)a.N * NAUG + r) * B + b] = y + mh;  // x(t_N); C stores the other nodes
     } else {
       // ---------------- C: objective ----------------
       // pc += W_A q1 + W_M (q2 + q3) + W_B q4 with the quadrature weights of the record table
@@ -273,6 +268,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       const double mh = P::row_shift(rp);  // the stage values arrive as Y - m_r/2
       double pc = 0.0, uprev2 = u0 * u0;
       double* xc = a.x + (size_t)G * B + b;
+      double* xr = a.x + (size_t)r * B + b;
       if (OUT_X && !fz) *xc = 0.0;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
@@ -306,7 +302,12 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             if (s + 1 < D) nxt = fetch(s + 1);
             __builtin_amdgcn_sched_barrier(0);
             const double uM2 = c.uM * c.uM, uB2 = c.uB * c.uB;
-            const double q1 = P::row_q(c.Y1 + mh, uprev2, rp), q2 = P::row_q(c.Y2 + mh, uM2, rp);
+            const double y1 = c.Y1 + mh;
+            if (OUT_X) {
+              if (!fz) *xr = y1;   // x(t_i)
+              xr += colB;
+            }
+            const double q1 = P::row_q(y1, uprev2, rp), q2 = P::row_q(c.Y2 + mh, uM2, rp);
             const double q3 = P::row_q(c.Y3 + mh, uM2, rp), q4 = P::row_q(c.Y4 + mh, uB2, rp);
             pc = __builtin_fma(c.wA, q1, __builtin_fma(c.wM, q2 + q3, __builtin_fma(c.wB, q4, pc)));
             if (OUT_X) {
