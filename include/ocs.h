@@ -223,6 +223,8 @@ typedef struct ocs_fbs_options {
   int nWINDOWS;         /* build option, default 0 = automatic (currently 1): with the fused update the batch can be cut
                            into this many windows that run their sweep loops on separate streams (marching kernels of
                            one window under the streaming kernels of another); results do not depend on it */
+  int cost_row;         /* default 0: the running-objective row of xaug (row nS) is left unspecified -- soln of the
+                           reference holds x, lam, u and the scalar J only (fb_sweep.m:117-125); 1 writes it */
 } ocs_fbs_options;
 int ocs_fbs_default_options(ocs_fbs_options *o);
 /* [x, lam(, J)] = compute_x_lam(_J)(prob, x0, tspan, u, RelTol, AbsTol)   compute_x_lam.m:1-19, compute_x_lam_J.m:1-21
@@ -237,7 +239,8 @@ int ocs_compute_x_lam_dev(ocs_integrator g, ocs_problem p, int batch, const doub
  * NULL for the default lower bound (:23).  sweeps[b] = sweep index at which instance b converged, 0 if it
  * never did (the reference then returns an empty struct, :77).  maxChange (nSWEEPS x batch, may be NULL)
  * holds the "Normalized change in u" of :109 per sweep (NaN where not run).  uInterp = soln.u sampled on
- * linspace(T0,TF,nINTERP_PTS) (:123).  Returns OCS_NUM_NOT_CONVERGED if any instance did not converge. */
+ * linspace(T0,TF,nINTERP_PTS) (:123).  Returns OCS_NUM_NOT_CONVERGED if any instance did not converge.
+ * _dev: xaug is [N+1][nS+1][batch]; its last row (the running objective) is written only with opt->cost_row. */
 int ocs_fb_sweep(ocs_integrator g, ocs_problem p, int batch, const double *x0, const ocs_fbs_options *opt,
                  const double *u0grid, const double *u0err, double *x, double *lam, double *uInterp, double *J,
                  int *sweeps, double *maxChange);

@@ -221,6 +221,7 @@ int ocs_fbs_default_options(ocs_fbs_options* o) {
   o->nINTERP_PTS = 1001;  // :22
   o->fused_update_off = 0;
   o->nWINDOWS = 0;
+  o->cost_row = 0;
   return OCS_OK;
 }
 
@@ -381,6 +382,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       fo.frozen = status + off;
       fo.dump = f->dump.d() + off;
       fo.ld = batch;
+      fo.no_cost_row = opt->cost_row == 0;
       LAUNCH_TRY(launch_forward(pj, gd, cnt, x0 + off, f->ugrid.d() + off, xaug + off, J + off, fo, st));
       if (sweep == 1 && j + 1 < nwin) HIP_TRY(hipEventRecord(f->stag, st));  // the next window starts one pass later
       LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, cnt, xaug + off, f->xmid.d() + off, st, batch));
@@ -425,6 +427,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     FwdOpts fo;
     fo.frozen = status;
     fo.dump = f->dump.d();
+    fo.no_cost_row = opt->cost_row == 0;  // soln holds x, lam, u and the scalar J (fb_sweep.m:117-125)
     LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
     // pchip midpoints of x: inside the costate and control kernels where the wave-specialised costate kernel applies
     const bool ownx = fusedup && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch);

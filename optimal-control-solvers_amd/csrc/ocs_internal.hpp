@@ -53,7 +53,8 @@ int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const
                        const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
                        hipStream_t s);
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                      double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s);
+                      double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s,
+                      bool no_cost_row = false);
 bool rowsplit_supported(Functor f, int nS, int nC);
 int launch_forward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, hipStream_t s);
@@ -80,6 +81,8 @@ struct FwdOpts {
   double* dump = nullptr;       // [B] scratch the stores of frozen trajectories go to
   int ld = 0;                   // row distance of the batch-minor arrays when the call covers a window of a larger
                                 // batch (pointers offset by the caller, `batch` = size of the window); 0 = batch
+  bool no_cost_row = false;     // the running-objective row of x may be left unwritten (only J is wanted); honoured
+                                // where it saves traffic (the pipeline kernel), ignored elsewhere
 };
 struct BwdOpts {
   int mapping = MAP_AUTO;

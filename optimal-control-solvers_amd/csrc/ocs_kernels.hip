@@ -180,7 +180,8 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
     if (N1 == 0 || (N1 < g.N && !x)) return -1;  // the split needs the boundary column in memory
     GridDesc g1 = g;
     g1.N = N1;
-    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s);
+    // (a split pass hands the running objective to the lane kernel through the boundary column: keep the row then)
+    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s, o.no_cost_row && N1 == g.N);
     if (rc || N1 == g.N) return rc;
     // remaining steps N1 .. N-1 on the lane kernel, continuing from column N1 (state rows and running objective)
     const size_t ldb = o.ld ? o.ld : batch;

@@ -118,6 +118,7 @@ struct FwdArgsPL {
   const int* frozen;  // optional [B]: trajectories with frozen[b] != 0 store nothing (as in FwdArgs)
   double* dump;       // [B] scratch for their stores
   int ld;             // row distance of the arrays when the launch covers a window of a larger batch; 0 = batch
+  int nocost;         // leave the running-objective row of x unwritten (J only)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -269,7 +270,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       double pc = 0.0, uprev2 = u0 * u0;
       double* xc = a.x + (size_t)G * B + b;
       double* xr = a.x + (size_t)r * B + b;
-      if (OUT_X && !fz) *xc = 0.0;
+      const bool wc = !fz && !a.nocost;  // the objective row is written
+      if (OUT_X && wc) *xc = 0.0;
       long long tb = 0, tc = 0;
       for (int k = 0; k <= nb; ++k) {
         const long long t0 = PL_T();
@@ -313,7 +315,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             if (OUT_X) {
               xc += colB;
               const double pcs = group_sum_pl<G>(pc);
-              if (!fz) *xc = pcs;
+              if (wc) *xc = pcs;
             }
             uprev2 = uB2;
           }
@@ -425,7 +427,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
     const bool fz = FRZ && a.frozen[b] != 0;
     const size_t colB = (size_t)NAUG * B;
     double carry = 0.0;  // running objective at the node before this lane's step (OUT_X) / this lane's share (else)
-    if (OUT_X && !fz && csub == 0) a.x[(size_t)G * B + b] = 0.0;
+    const bool wc = !fz && !a.nocost;  // the objective row is written
+    if (OUT_X && wc && csub == 0) a.x[(size_t)G * B + b] = 0.0;
     long long tb = 0, tc = 0;
     for (int k = 0; k <= nb; ++k) {
       const long long t0 = PL_T();
@@ -491,7 +494,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
               double* xn = a.x + (size_t)(j * D + s) * colB + b;  // node i = j D + s
 #pragma unroll
               for (int q = 0; q < G; ++q) xn[(size_t)q * B] = Y1[q];
-              xn[colB + (size_t)G * B] = tot;                      // objective at node i + 1
+              if (wc) xn[colB + (size_t)G * B] = tot;              // objective at node i + 1
             }
             carry = (G == 1) ? tot : dpp_quad_pl<(G == 4) ? 0xFF : 0xF5>(tot);  // the pass's last lane
           } else {
@@ -1206,9 +1209,10 @@ static void run_forward_pl(const FwdArgsPL& a, hipStream_t s) {
   }
 }
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
-                      double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s) {
+                      double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s,
+                      bool no_cost_row) {
   if (!pipeline_shape_ok(p.nS, g.N, batch, false) || (frozen && !dump)) return -1;
-  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump, ld};
+  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump, ld, no_cost_row ? 1 : 0};
 #ifdef OCS_PL_STAMPS
   static long long* dbg = nullptr;
   const int nwg = batch / (64 / p.nS);

@@ -203,3 +203,23 @@ def test_batched_vector_interpolant_on_device(ocs, oracle, n, nComp, batch, nq):
             assert np.allclose(got[:, :, b].T, ref, rtol=1e-12, atol=1e-13, equal_nan=True), (name, b)
             if name == "previous":
                 assert np.array_equal(got[:, :, b].T, ref, equal_nan=True), (name, b)
+
+
+def test_cost_row_option(ocs):
+    """soln of the reference carries x, lam, u and the scalar J (fb_sweep.m:117-125); the running-objective row of the
+    augmented state is written only on request.  With it: its last column is J and its first 0; the other outputs do
+    not depend on the option."""
+    import torch
+    rng = np.random.default_rng(8)
+    B, N = 128, 400
+    x0 = torch.tensor(rng.uniform(0.5, 2.5, (1, B)), device="cuda:0")
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], rng.uniform(1.0, 2.0, B)[None, :])
+    integ = ocs.RK4Integrator(ocs.linspace(0, 10, N + 1))
+    ra = ocs.fb_sweep_dev(prob, integ, x0)
+    rb = ocs.fb_sweep_dev(prob, integ, x0, {"cost_row": 1})
+    xa, xb = ra["xaug"].cpu().numpy(), rb["xaug"].cpu().numpy()
+    assert np.array_equal(xa[:, 0, :], xb[:, 0, :]) and torch.equal(ra["J"], rb["J"]) and torch.equal(ra["u"], rb["u"])
+    assert torch.equal(ra["lam"], rb["lam"]) and torch.equal(ra["sweeps"], rb["sweeps"])
+    assert np.all(xb[0, 1, :] == 0.0) and np.array_equal(xb[-1, 1, :], rb["J"].cpu().numpy())
+    assert np.all(np.diff(xb[:, 1, :], axis=0) > 0)          # the integrand x^2 + c u^2 is positive
