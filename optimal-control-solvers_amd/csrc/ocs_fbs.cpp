@@ -420,7 +420,57 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     nactive = 0;
     for (int j = 0; j < nwin; ++j) nactive += act[j];
   }
-  for (int sweep = 1; !(fusedup && nwin > 1) && sweep <= opt->nSWEEPS && nactive > 0; ++sweep) {  // :79
+  // ---- fused update, one stream, sweeps enqueued one ahead --------------------------------------------------------
+  // The host learns the number of active instances of sweep k only after a round trip; waiting for it before
+  // enqueuing sweep k+1 left the GPU idle for ~25 us per sweep.  Here sweep k+1 is enqueued first and its kernels
+  // start with a look at sweep k's device counter: if no instance was left, they return at once (a sweep over
+  // converged instances would change nothing anyway -- they are frozen -- but would cost its full time).
+  bool spec_done = false;
+  if (fusedup && nwin == 1 && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch) &&
+      forward_gate_supported(pd, gd, batch)) {
+    const int nsw = opt->nSWEEPS;
+    if (f->h_nact_cap < nsw) {
+      if (f->h_nact) (void)hipHostFree(f->h_nact);
+      f->h_nact = nullptr;
+      HIP_TRY(hipHostMalloc((void**)&f->h_nact, sizeof(int) * (size_t)nsw));
+      f->h_nact_cap = nsw;
+    }
+    while (f->wevents.size() < 2) {
+      hipEvent_t ev;
+      HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+      f->wevents.push_back(ev);
+    }
+    OCS_TRY(f->nact_slots.ensure(sizeof(int) * (size_t)nsw));
+    HIP_TRY(hipMemsetAsync(f->nact_slots.p, 0, sizeof(int) * (size_t)nsw, s));
+    int* dslots = (int*)f->nact_slots.p;
+    auto enqueue = [&](int sweep) -> int {
+      const int* gate = sweep > 1 ? dslots + (sweep - 2) : nullptr;  // active instances after the sweep before
+      FwdOpts fo;
+      fo.frozen = status;
+      fo.dump = f->dump.d();
+      fo.no_cost_row = opt->cost_row == 0;
+      fo.gate = gate;
+      LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
+      LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, nullptr, f->ugrid.d(), status, f->dump.d(), lam, s, 0, tb.PR,
+                                gate));
+      LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, nullptr, lam, f->ugrid.d(), status, f->metric.d(),
+                                     opt->uRelTol, opt->uAbsTol, s, 0, gate));
+      LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
+                                    mc, dslots + (sweep - 1), s, 0, gate));
+      HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+      HIP_TRY(hipEventRecord(f->wevents[sweep & 1], s));
+      return OCS_OK;
+    };
+    OCS_TRY(enqueue(1));
+    for (int sweep = 1; sweep <= nsw; ++sweep) {
+      if (sweep < nsw) OCS_TRY(enqueue(sweep + 1));
+      HIP_TRY(hipEventSynchronize(f->wevents[sweep & 1]));
+      nactive = f->h_nact[sweep - 1];
+      if (nactive == 0) break;  // the sweep already enqueued finds its gate closed
+    }
+    spec_done = true;
+  }
+  for (int sweep = 1; !spec_done && !(fusedup && nwin > 1) && sweep <= opt->nSWEEPS && nactive > 0; ++sweep) {  // :79
     // uNew = sweep(u): compute_x_lam (:95) ...
     // instances that converged in an earlier sweep are integrated along but store nothing: their x, lam, J stay
     // those of the sweep they converged in (final_sweep(u), :82)

@@ -363,11 +363,13 @@ struct ControlGridArgs {
   double* metric;
   double relTol, absTol;
   int ld;  // row distance when the launch covers a window of a larger batch; 0 = batch
+  const int* gate;  // optional: the launch does nothing if *gate == 0
 };
 
 template <class P>
 __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU, R = kPchipRun;
+  if (a.gate && *a.gate == 0) return;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int i0 = blockIdx.y * R;  // first interval of this thread's run
   if (b >= a.batch || a.status[b] != 0) return;
@@ -609,7 +611,9 @@ __global__ void k_tu_at(int nq, const double* __restrict__ tq, const double* __r
 // ---------------------------------------------------------------------------------------
 __global__ void k_fbs_advance(int batch, int sweep, int nparts, const double* __restrict__ metric,
                               int* __restrict__ anyvalid, int* __restrict__ usel, int* __restrict__ status,
-                              double* __restrict__ maxChange, int* __restrict__ nactive, int ldb) {
+                              double* __restrict__ maxChange, int* __restrict__ nactive, int ldb,
+                              const int* __restrict__ gate) {
+  if (gate && *gate == 0) return;  // a sweep enqueued ahead of the verdict of the one before, which was the last
   const size_t ld = (size_t)(ldb ? ldb : batch);  // row distance of metric / maxChange
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   bool still = false;

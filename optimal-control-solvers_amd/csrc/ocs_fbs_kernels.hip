@@ -51,13 +51,13 @@ static void run_costate(const CostateArgs& a, hipStream_t s) {
 }
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb,
-                   const double* PR) {
+                   const double* PR, const int* gate) {
   if (frozen && !dump) return -1;
   // the wave-specialised kernel while its workgroups (one per 64/nS instances) fit on the chip in two rounds
   if (costate_forms_midpoints(p, g.N, batch))
     return xmid ? launch_costate_pl(p, g, batch, x, ldx, xmid, frozen, dump, lam, ldb, s)
-                : launch_costate_plx(p, g, batch, x, ldx, PR, frozen, dump, lam, ldb, s);
-  if (!xmid) return -1;
+                : launch_costate_plx(p, g, batch, x, ldx, PR, frozen, dump, lam, ldb, s, gate);
+  if (!xmid || gate) return -1;
   const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam, ldb};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
@@ -75,9 +75,9 @@ static void run_control_grid(const ControlGridArgs& a, hipStream_t s) {
 int control_grid_parts(int N) { return (N + kPchipRun - 1) / kPchipRun; }
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
-                        double relTol, double absTol, hipStream_t s, int ldb) {
+                        double relTol, double absTol, hipStream_t s, int ldb, const int* gate) {
   const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, make_tab(t), t.TM, u,
-                          status, metric, relTol, absTol, ldb};
+                          status, metric, relTol, absTol, ldb, gate};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, (g.N + kPchipRun - 1) / kPchipRun), dim3(256), args, s);
@@ -131,9 +131,9 @@ int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* 
 
 int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
-                       double* maxChange, int* nactive, hipStream_t s, int ldb) {
+                       double* maxChange, int* nactive, hipStream_t s, int ldb, const int* gate) {
   k_fbs_advance<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, sweep, nparts, metric, anyvalid, usel, status,
-                                                                 maxChange, nactive, ldb);
+                                                                 maxChange, nactive, ldb, gate);
   return hip_rc3(hipGetLastError());
 }
 

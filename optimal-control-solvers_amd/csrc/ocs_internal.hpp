@@ -45,7 +45,7 @@ bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch);
 // the same forming the pchip midpoints of x itself (no xmid array); PR: [N][costate_prec()] interval records
 int costate_prec();
 int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
-                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s);
+                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s, const int* gate = nullptr);
 int launch_costate_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s);
 // pend0: optional [B], the k1 half of column 2N of dJdu when the steps above N were integrated by another kernel
@@ -54,7 +54,9 @@ int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const
                        hipStream_t s);
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s,
-                      bool no_cost_row = false);
+                      bool no_cost_row = false, const int* gate = nullptr);
+// whether launch_forward with these shapes runs the one kernel that honours FwdOpts::gate
+bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch);
 bool rowsplit_supported(Functor f, int nS, int nC);
 int launch_forward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, hipStream_t s);
@@ -81,6 +83,8 @@ struct FwdOpts {
   double* dump = nullptr;       // [B] scratch the stores of frozen trajectories go to
   int ld = 0;                   // row distance of the batch-minor arrays when the call covers a window of a larger
                                 // batch (pointers offset by the caller, `batch` = size of the window); 0 = batch
+  const int* gate = nullptr;    // device flag: the launch does nothing if *gate == 0 (only where
+                                // forward_gate_supported says so; otherwise the call fails)
   bool no_cost_row = false;     // the running-objective row of x may be left unwritten (only J is wanted); honoured
                                 // where it saves traffic (the pipeline kernel), ignored elsewhere
 };
@@ -149,7 +153,8 @@ int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const dou
 bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb = 0,
-                   const double* PR = nullptr);  // xmid == NULL with PR: the kernel forms the midpoints (see below)
+                   const double* PR = nullptr,   // xmid == NULL with PR: the kernel forms the midpoints (see below)
+                   const int* gate = nullptr);   // only with xmid == NULL
 // metric (optional): [control_grid_parts(N)][B] partial maxima of the weighted change at the grid nodes (error points
 // == nodes), for launch_fbs_advance
 // batched single shooting (ocs_shooting.cpp): per-instance state of the spectral projected gradient iteration,
@@ -172,7 +177,7 @@ int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* 
                   const double* V, double* out, hipStream_t s);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
-                        double relTol, double absTol, hipStream_t s, int ldb = 0);
+                        double relTol, double absTol, hipStream_t s, int ldb = 0, const int* gate = nullptr);
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
                        const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
@@ -180,7 +185,7 @@ int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const i
 int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
 int control_pts_parts(int nq);  // rows of the partial-maximum array `metric` [parts][B] that launch_control_pts fills
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
-                       double* maxChange, int* nactive, hipStream_t s, int ldb = 0);
+                       double* maxChange, int* nactive, hipStream_t s, int ldb = 0, const int* gate = nullptr);
 
 // registry queries (host)
 bool functor_supported(Functor f, int nS, int nC);

@@ -169,8 +169,15 @@ static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested,
   return MAP_LANE;
 }
 
+bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
+  if (p.functor == Functor::LQ) return false;
+  return choose_mapping(p, g.N, batch, MAP_AUTO, true, false, true) == MAP_PIPELINE &&
+         pipeline_steps(p, g.N, batch, false) == g.N;
+}
+
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
+  if (o.gate && (o.mapping != MAP_AUTO || o.uconst || o.Jadd || !forward_gate_supported(p, g, batch))) return -1;
   if (p.functor == Functor::LQ) return launch_forward_lq(p, g, batch, x0, u, x, J, o, s);
   const bool plain = !o.uconst && !o.Jadd;
   int map = choose_mapping(p, g.N, batch, o.mapping, plain, false, x != nullptr);
@@ -181,7 +188,7 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
     GridDesc g1 = g;
     g1.N = N1;
     // (a split pass hands the running objective to the lane kernel through the boundary column: keep the row then)
-    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s, o.no_cost_row && N1 == g.N);
+    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s, o.no_cost_row && N1 == g.N, o.gate);
     if (rc || N1 == g.N) return rc;
     // remaining steps N1 .. N-1 on the lane kernel, continuing from column N1 (state rows and running objective)
     const size_t ldb = o.ld ? o.ld : batch;

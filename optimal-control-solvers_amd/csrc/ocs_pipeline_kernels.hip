@@ -119,6 +119,8 @@ struct FwdArgsPL {
   double* dump;       // [B] scratch for their stores
   int ld;             // row distance of the arrays when the launch covers a window of a larger batch; 0 = batch
   int nocost;         // leave the running-objective row of x unwritten (J only)
+  const int* gate;    // optional: the launch does nothing if *gate == 0 (a sweep enqueued before the previous one's
+                      // count of active instances is known, fb_sweep)
 };
 
 // ---------------------------------------------------------------------------------------
@@ -146,6 +148,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int nb = a.N / D;
   const int bw = blockIdx.x * TPW;  // first trajectory of this workgroup
+  if (a.gate && *a.gate == 0) return;
 
   if (wave == 0) {
     // ---------------- M: HBM -> LDS ----------------
@@ -953,6 +956,7 @@ struct CostateXCfg {
 struct CostateXArgs {
   CostateArgsPL c;     // c.xmid is not used
   const double* PR;    // [N][kPRec]
+  const int* gate;     // optional: the launch does nothing if *gate == 0
 };
 
 __device__ static inline double pchip_end_pl(double h0, double h1, double del0, double del1) {
@@ -1037,6 +1041,7 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int N = a.N, nb = N / D;
   const int bw = blockIdx.x * TPW;
+  if (aa.gate && *aa.gate == 0) return;
   if (wave == 0) {
     // ---------------- M: HBM -> LDS ----------------
     auto issue = [&](int j) OCS_INLINE {
@@ -1142,9 +1147,9 @@ int costate_prec() { return kPRec; }
 bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch);
 // PR: [N][costate_prec()] interval records; the midpoints are formed inside (no xmid array)
 int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
-                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s) {
+                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s, const int* gate) {
   if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || (frozen && !dump) || !PR) return -1;
-  const CostateXArgs a{CostateArgsPL{g.N, batch, ld, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, frozen, dump, lam}, PR};
+  const CostateXArgs a{CostateArgsPL{g.N, batch, ld, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, frozen, dump, lam}, PR, gate};
   if (p.nS == 1)
     run_costate_plx<LogisticK<1>>(a, s);
   else if (p.nS == 2)
@@ -1210,9 +1215,9 @@ static void run_forward_pl(const FwdArgsPL& a, hipStream_t s) {
 }
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s,
-                      bool no_cost_row) {
+                      bool no_cost_row, const int* gate) {
   if (!pipeline_shape_ok(p.nS, g.N, batch, false) || (frozen && !dump)) return -1;
-  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump, ld, no_cost_row ? 1 : 0};
+  FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump, ld, no_cost_row ? 1 : 0, gate};
 #ifdef OCS_PL_STAMPS
   static long long* dbg = nullptr;
   const int nwg = batch / (64 / p.nS);
