@@ -223,3 +223,33 @@ def test_cost_row_option(ocs):
     assert torch.equal(ra["lam"], rb["lam"]) and torch.equal(ra["sweeps"], rb["sweeps"])
     assert np.all(xb[0, 1, :] == 0.0) and np.array_equal(xb[-1, 1, :], rb["J"].cpu().numpy())
     assert np.all(np.diff(xb[:, 1, :], axis=0) > 0)          # the integrand x^2 + c u^2 is positive
+
+
+@pytest.mark.parametrize("nSWEEPS", [1, 3, 40])
+def test_sweeps_enqueued_ahead_equal_the_plain_loop(ocs, nSWEEPS):
+    """On shapes the wave-specialised kernels take, sweep k+1 is enqueued before the host knows how many instances
+    sweep k left active (its kernels return at once if none).  Same results as the loop that waits, also when the
+    sweep limit ends the solve (no instance / not every instance converged: fb_sweep.m:77, :86)."""
+    import torch
+    rng = np.random.default_rng(3)
+    B, N = 192, 160
+    x0 = torch.tensor(rng.uniform(0.5, 2.5, (1, B)), device="cuda:0")
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], rng.uniform(1.0, 2.0, B)[None, :])
+    integ = ocs.RK4Integrator(ocs.linspace(0, 10, N + 1))
+    ra = ocs.fb_sweep_dev(prob, integ, x0, {"nSWEEPS": nSWEEPS, "nERROR_PTS": N + 1, "nINTERP_PTS": 41})
+    rb = ocs.fb_sweep_dev(prob, integ, x0, {"nSWEEPS": nSWEEPS, "nERROR_PTS": N + 1, "nINTERP_PTS": 41,
+                                            "fused_update_off": 2})
+    assert torch.equal(ra["sweeps"], rb["sweeps"]) and ra["status"] == rb["status"]
+    sw = ra["sweeps"].cpu().numpy()
+    if nSWEEPS == 1:
+        assert sw.max() == 0 and ra["status"] == 2            # OCS_NUM_NOT_CONVERGED: nobody converges in one sweep
+    if nSWEEPS == 40:
+        assert sw.min() > 0 and ra["status"] == 0
+    for key in ("xaug", "lam", "u", "J"):
+        a, b = ra[key].cpu().numpy(), rb[key].cpu().numpy()
+        if key == "xaug":
+            a, b = a[:, :1, :], b[:, :1, :]
+        assert relerr(a, b) < 1e-12, key
+    ma, mb = ra["maxChange"].cpu().numpy(), rb["maxChange"].cpu().numpy()
+    assert np.array_equal(np.isnan(ma), np.isnan(mb)) and relerr(np.nan_to_num(ma), np.nan_to_num(mb)) < 1e-6
