@@ -553,7 +553,8 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   using C_ = PLCfg<G, true>;
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
   constexpr int UOFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::U_DBL;
-  __shared__ __attribute__((aligned(16))) double ra[2][3][D][64];      // R -> A: Y2, Y3, Y4 (Y1 = x_i is in the input slot)
+  // R -> A: the four stage states as two 16-byte pairs (Y1, Y2), (Y3, Y4): two LDS instructions on either side
+  __shared__ __attribute__((aligned(16))) double2 ra[2][2][D][64];
   __shared__ __attribute__((aligned(16))) double ad[2][3][D][64];      // A -> D: k1, k2 + k3, k4
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT]; // {records | u | checkpoints}
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -625,7 +626,7 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
         const double* slot = &inp[k % NSLOT][0];
         const double* us = slot + UOFF + tl;
         const double* xs = slot + XOFF + r * TPW + tl;
-        double* w = &ra[k & 1][0][0][lane];
+        double2* w = &ra[k & 1][0][0][lane];
         struct In { double h, hh, xi, uA, uM; };
         auto fetch = [&](int s) OCS_INLINE {  // s-th step processed = local ascending index D-1-s
           const int l = D - 1 - s;
@@ -649,9 +650,8 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
           const double Y3 = __builtin_fma(c.hh, f, c.xi);
           f = P::row_f(Y3, c.uM, rp);
           const double Y4 = __builtin_fma(c.h, f, c.xi);
-          w[(0 * D + s) * 64] = Y2;
-          w[(1 * D + s) * 64] = Y3;
-          w[(2 * D + s) * 64] = Y4;
+          w[(0 * D + s) * 64] = double2{c.xi, Y2};
+          w[(1 * D + s) * 64] = double2{Y3, Y4};
         }
       }
       tc += PL_T() - t1;
@@ -677,9 +677,8 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
       if (k >= 1 && k <= nb) {
         const int j = k - 1;
         const double* slot = &inp[j % NSLOT][0];
-        const double* w = &ra[j & 1][0][0][lane];
+        const double2* w = &ra[j & 1][0][0][lane];
         double* kw = &ad[j & 1][0][0][lane];
-        const double* xs = slot + XOFF + r * TPW + tl;
         struct In { double h, hh, h6, h3, e4, e3, e1, Y1, Y2, Y3, Y4; };
         auto fetch = [&](int s) OCS_INLINE {
           const int l = D - 1 - s;
@@ -691,10 +690,11 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
           v.e4 = slot[RS * l + SCO];
           v.e3 = slot[RS * l + SCO + 1];
           v.e1 = slot[RS * l + SCO + 2];
-          v.Y1 = xs[l * 64];
-          v.Y2 = w[(0 * D + s) * 64];
-          v.Y3 = w[(1 * D + s) * 64];
-          v.Y4 = w[(2 * D + s) * 64];
+          const double2 p12 = w[(0 * D + s) * 64], p34 = w[(1 * D + s) * 64];
+          v.Y1 = p12.x;
+          v.Y2 = p12.y;
+          v.Y3 = p34.x;
+          v.Y4 = p34.y;
           return v;
         };
         In nxt = fetch(0);
