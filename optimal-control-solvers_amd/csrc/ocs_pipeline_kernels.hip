@@ -139,8 +139,10 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
   // [buffer][Y1..Y4][step][lane], the step stride padded so that the objective wave, whose lanes of a trajectory
   // take consecutive steps, reads G rows of a step per lane without bank conflicts
-  constexpr int SS = (G == 1) ? 64 : 72;
-  __shared__ __attribute__((aligned(16))) double stage[2][4][D][SS];
+  // (pairs (Y1, Y2), (Y3, Y4): two 16-byte LDS instructions per step on the writing side; with 65 elements per step
+  //  the G lanes of a trajectory in C, one step apart, sit 16 bytes apart in the banks)
+  constexpr int SS = (G == 1) ? 64 : 65;
+  __shared__ __attribute__((aligned(16))) double2 stage[2][2][D][SS];
   __shared__ double ulast[2][64];  // control sample at the first node of a block (S -> C)
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];  // [slot]{records | u}
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -220,7 +222,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
         if (k < nb) {
           const double* rec = &inp[k % NSLOT][0];
           const double* us = rec + C_::REC_DBL + tl;
-          double* w = &stage[k & 1][0][0][lane];
+          double2* w = &stage[k & 1][0][0][lane];
           // LDS reads of step s+1 are issued before step s is computed (LDS latency ~100 cycles would
           // otherwise sit on every step: the scheduler keeps loads next to their uses)
           struct In { double h, hh, h6, uM, uB; };
@@ -240,16 +242,15 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             if (s + 1 < D) nxt = fetch(s + 1);
             __builtin_amdgcn_sched_barrier(0);
             const double cM = P::row_vertex(mh, c.uM), cB = P::row_vertex(mh, c.uB);
-            w[s * SS] = y;                                 // Y1 - m/2
             const double F1 = P::row_f_shifted(y, cprev);
             double Y = __builtin_fma(c.hh, F1, y);
-            w[(D + s) * SS] = Y;                           // Y2 - m/2
+            w[s * SS] = double2{y, Y};                     // (Y1, Y2) - m/2
             const double F2 = P::row_f_shifted(Y, cM);
             Y = __builtin_fma(c.hh, F2, y);
-            w[(2 * D + s) * SS] = Y;                       // Y3 - m/2
+            const double Y3 = Y;
             const double F3 = P::row_f_shifted(Y, cM);
             Y = __builtin_fma(c.h, F3, y);
-            w[(3 * D + s) * SS] = Y;                       // Y4 - m/2
+            w[(D + s) * SS] = double2{Y3, Y};              // (Y3, Y4) - m/2
             const double F4 = P::row_f_shifted(Y, cB);
             y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
             cprev = cB;
@@ -285,7 +286,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
           const int j = k - 1;
           const double* rec = &inp[j % NSLOT][0];
           const double* us = rec + C_::REC_DBL + tl;
-          const double* w = &stage[j & 1][0][0][lane];
+          const double2* w = &stage[j & 1][0][0][lane];
           struct In { double wA, wM, wB, uM, uB, Y1, Y2, Y3, Y4; };
           auto fetch = [&](int s) OCS_INLINE {
             In v;
@@ -294,10 +295,11 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             v.wB = rec[RS * s + SCO + 5];
             v.uM = us[(2 * s) * TPW];
             v.uB = us[(2 * s + 1) * TPW];
-            v.Y1 = w[s * SS];
-            v.Y2 = w[(D + s) * SS];
-            v.Y3 = w[(2 * D + s) * SS];
-            v.Y4 = w[(3 * D + s) * SS];
+            const double2 p12 = w[s * SS], p34 = w[(D + s) * SS];
+            v.Y1 = p12.x;
+            v.Y2 = p12.y;
+            v.Y3 = p34.x;
+            v.Y4 = p34.y;
             return v;
           };
           In nxt = fetch(0);
@@ -360,7 +362,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
       if (k < nb) {
         const double* rec = &inp[k % NSLOT][0];
         const double* us = rec + C_::REC_DBL + tl;
-        double* w = &stage[k & 1][0][0][lane];
+        double2* w = &stage[k & 1][0][0][lane];
         ulast[k & 1][lane] = uprev;
         // LDS reads of step s+1 are issued before step s is computed (LDS latency ~100 cycles would
         // otherwise sit on every step: the scheduler keeps loads next to their uses)
@@ -381,16 +383,15 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
           if (s + 1 < D) nxt = fetch(s + 1);
           __builtin_amdgcn_sched_barrier(0);
           const double cM = P::row_vertex(mh, c.uM), cB = P::row_vertex(mh, c.uB);
-          w[s * SS] = y;                                 // Y1 - m/2
           const double F1 = P::row_f_shifted(y, cprev);
           double Y = __builtin_fma(c.hh, F1, y);
-          w[(D + s) * SS] = Y;                           // Y2 - m/2
+          w[s * SS] = double2{y, Y};                     // (Y1, Y2) - m/2
           const double F2 = P::row_f_shifted(Y, cM);
           Y = __builtin_fma(c.hh, F2, y);
-          w[(2 * D + s) * SS] = Y;                       // Y3 - m/2
+          const double Y3 = Y;
           const double F3 = P::row_f_shifted(Y, cM);
           Y = __builtin_fma(c.h, F3, y);
-          w[(3 * D + s) * SS] = Y;                       // Y4 - m/2
+          w[(D + s) * SS] = double2{Y3, Y};              // (Y3, Y4) - m/2
           const double F4 = P::row_f_shifted(Y, cB);
           y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
           cprev = cB;
@@ -442,7 +443,7 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
         const int j = k - 1;
         const double* rec = &inp[j % NSLOT][0];
         const double* us = rec + C_::REC_DBL + ctl;
-        const double* st = &stage[j & 1][0][0][ctl * G];
+        const double2* st = &stage[j & 1][0][0][ctl * G];
         const double ublk = ulast[j & 1][ctl * G];
         // all LDS reads of the block first (the passes below then wait for their own only)
         struct In { double wA, wM, wB, uA, uM, uB, Y[4][G]; };
@@ -458,9 +459,13 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
           v.uB = us[(2 * s + 1) * TPW];
           v.uA = us[(s > 0 ? 2 * s - 1 : 0) * TPW];
 #pragma unroll
-          for (int jj = 0; jj < 4; ++jj)
+          for (int pp = 0; pp < 2; ++pp)
 #pragma unroll
-            for (int q = 0; q < G; ++q) v.Y[jj][q] = st[(jj * D + s) * SS + q];
+            for (int q = 0; q < G; ++q) {
+              const double2 pr = st[(pp * D + s) * SS + q];
+              v.Y[2 * pp][q] = pr.x;
+              v.Y[2 * pp + 1][q] = pr.y;
+            }
         }
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
