@@ -560,7 +560,10 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   constexpr int UOFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::U_DBL;
   // R -> A: the four stage states as two 16-byte pairs (Y1, Y2), (Y3, Y4): two LDS instructions on either side
   __shared__ __attribute__((aligned(16))) double2 ra[2][2][D][64];
-  __shared__ __attribute__((aligned(16))) double ad[2][3][D][64];      // A -> D: k1, k2 + k3, k4
+  // A -> D: k1, k2 + k3, k4 and lam(t_i).  D takes G consecutive steps of a trajectory per lane, i.e. reads the G rows
+  // of a step: the padded step stride keeps those 16-byte reads of the lanes of a quad in different banks
+  constexpr int KS = (G == 1) ? 64 : 72;
+  __shared__ __attribute__((aligned(16))) double ad[2][4][D][KS];
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT]; // {records | u | checkpoints}
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -671,8 +674,7 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
   } else if (wave == 2) {
     // ---------------- A: adjoint recursion ----------------
     double lam = a.lamT ? a.lamT[(size_t)r * B + b] : 0.0;
-    double* ls = a.lam + (size_t)N * colB + (size_t)r * B + b;
-    if (OUT_LAM) *ls = lam;
+    if (OUT_LAM) a.lam[(size_t)N * colB + (size_t)r * B + b] = lam;
     long long tb = 0, tc = 0;
     for (int k = 0; k <= nb + 1; ++k) {
       const long long t0 = PL_T();
@@ -723,14 +725,11 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
           const double g0 = P::row_dfdx(c.Y1, k1, ev1, rp);        // :87-88
           lam = acc + g0;
           if (OUT_DJDU) {
-            kw[(0 * D + s) * 64] = k1;
-            kw[(1 * D + s) * 64] = k2 + k3;
-            kw[(2 * D + s) * 64] = k4;
+            kw[(0 * D + s) * KS] = k1;
+            kw[(1 * D + s) * KS] = k2 + k3;
+            kw[(2 * D + s) * KS] = k4;
           }
-          if (OUT_LAM) {
-            ls -= colB;
-            *ls = lam;
-          }
+          if (OUT_LAM) kw[(3 * D + s) * KS] = lam;  // stored by D
         }
       }
       tc += PL_T() - t1;
@@ -747,52 +746,93 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
       a.lam0[(size_t)G * B + b] = lamc;
     }
   } else {
-    // ---------------- D: dJdu columns ----------------
-    double* dp = a.dJdu + (size_t)(2 * N) * B + b;  // dJdu(2N+1), walks down
-    double cunext = rp.cw * a.u[(size_t)(2 * N) * B + b];
-    double pend = (a.pend0 && r == 0) ? a.pend0[b] : 0.0;  // summed over the rows of a trajectory below
+    // ---------------- D: dJdu columns and the stores of lam ----------------
+    // Lane (trajectory ctl, step csub of a pass of G steps; processed order, i.e. descending time) adds the rows itself:
+    //   column 2i+2 = B'k1 of step i+1 + B'k4 of step i,  column 2i+1 = B'(k2 + k3) at the midpoint   (:97-121)
+    //   with sum_r row_dfdu(cw_r u, k_r, ev) = row_dfdu(cws u, sum_r k_r, ev)  (linear in both)
+    // The two halves of a node column meet through a lane shift; every column and every lam value is stored once.
+    const int csub = lane % G, ctl = lane / G;
+    const int bx = bw + ctl;
+    double cws = 0.0;
+#pragma unroll
+    for (int q = 0; q < G; ++q)
+      cws += P::load_row([&](int k) OCS_INLINE {
+        return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + bx] : PS[k];
+      }, q).cw;
+    const double lamcx = a.lamT ? a.lamT[(size_t)G * B + bx] : 1.0;
+    // carried from pass to pass by the lane of the last (lowest) step: its B'k1 and its node control
+    double pend = a.pend0 ? a.pend0[bx] : 0.0;
+    double ucar = OUT_DJDU ? a.u[(size_t)(2 * N) * B + bx] : 0.0;
     long long tb = 0, tc = 0;
     for (int k = 0; k <= nb + 1; ++k) {
       const long long t0 = PL_T();
       lds_barrier();
       const long long t1 = PL_T();
       tb += t1 - t0;
-      if (OUT_DJDU && k >= 2) {
+      if (k >= 2) {
         const int j = k - 2;
         const double* slot = &inp[j % NSLOT][0];
-        const double* us = slot + UOFF + tl;
-        const double* kw = &ad[j & 1][0][0][lane];
-        struct In { double e4, e3, e1, uA, uM, k1, k23, k4; };
-        auto fetch = [&](int s) OCS_INLINE {
-          const int l = D - 1 - s;
-          In v;
-          v.e4 = slot[RS * l + SCO];
-          v.e3 = slot[RS * l + SCO + 1];
-          v.e1 = slot[RS * l + SCO + 2];
-          v.uA = us[(2 * l) * TPW];
-          v.uM = us[(2 * l + 1) * TPW];
-          v.k1 = kw[(0 * D + s) * 64];
-          v.k23 = kw[(1 * D + s) * 64];
-          v.k4 = kw[(2 * D + s) * 64];
-          return v;
-        };
-        In nxt = fetch(0);
+        const double* us = slot + UOFF + ctl;
+        const double* kw = &ad[j & 1][0][0][ctl * G];
+        // every LDS read of the block first, then the arithmetic
+        struct In { double e4, e3, e1, uA, uM, k1[G], k23[G], k4[G], lm[G]; };
+        In in[D / G];
 #pragma unroll
-        for (int s = 0; s < D; ++s) {
-          const In c = nxt;
-          if (s + 1 < D) nxt = fetch(s + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          const double ev4 = LT ? c.e4 * lamc : c.e4, ev3 = LT ? c.e3 * lamc : c.e3, ev1 = LT ? c.e1 * lamc : c.e1;
-          const double cuA = rp.cw * c.uA, cuM = rp.cw * c.uM;
-          const double p4 = P::row_dfdu(cunext, c.k4, ev4), p1 = P::row_dfdu(cuA, c.k1, ev1);
-          // p2 + p3 = (cuM ev3 - k2) + (cuM ev3 - k3) = 2 cuM ev3 - (k2 + k3)
-          const double p23 = __builtin_fma(cuM + cuM, ev3, -c.k23);
-          *dp = group_sum_pl<G>(pend + p4);   // column 2i+2
-          dp -= B;
-          *dp = group_sum_pl<G>(p23);         // column 2i+1
-          dp -= B;
-          pend = p1;
-          cunext = cuA;
+        for (int p0 = 0; p0 < D; p0 += G) {
+          const int s = p0 + csub, l = D - 1 - s;
+          In& v = in[p0 / G];
+          if (OUT_DJDU) {
+            v.e4 = slot[RS * l + SCO];
+            v.e3 = slot[RS * l + SCO + 1];
+            v.e1 = slot[RS * l + SCO + 2];
+            v.uA = us[(2 * l) * TPW];
+            v.uM = us[(2 * l + 1) * TPW];
+          }
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            if (OUT_DJDU) {
+              v.k1[q] = kw[(0 * D + s) * KS + q];
+              v.k23[q] = kw[(1 * D + s) * KS + q];
+              v.k4[q] = kw[(2 * D + s) * KS + q];
+            }
+            if (OUT_LAM) v.lm[q] = kw[(3 * D + s) * KS + q];
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        const int i0 = N - 1 - j * D - csub;  // this lane's step in the first pass
+#pragma unroll
+        for (int p0 = 0; p0 < D; p0 += G) {
+          const In& c = in[p0 / G];
+          const int i = i0 - p0;
+          if (OUT_LAM) {
+            double* lp = a.lam + (size_t)i * colB + bx;
+#pragma unroll
+            for (int q = 0; q < G; ++q) lp[(size_t)q * B] = c.lm[q];
+          }
+          if (OUT_DJDU) {
+            const double ev4 = LT ? c.e4 * lamcx : c.e4, ev3 = LT ? c.e3 * lamcx : c.e3, ev1 = LT ? c.e1 * lamcx : c.e1;
+            double S1 = c.k1[0], S23 = c.k23[0], S4 = c.k4[0];
+#pragma unroll
+            for (int q = 1; q < G; ++q) {
+              S1 += c.k1[q];
+              S23 += c.k23[q];
+              S4 += c.k4[q];
+            }
+            // the node above this step: its control and its B'k1 sit in the lane of the step processed just before
+            const double un_s = (G == 1) ? ucar : dpp_quad_pl<(G == 4) ? 0x90 : 0xA0>(c.uA);
+            const double unext = csub ? un_s : ucar;
+            const double p1 = P::row_dfdu(cws * c.uA, S1, ev1);
+            const double p4 = P::row_dfdu(cws * unext, S4, ev4);
+            const double cuM = cws * c.uM;
+            const double p23 = P::row_dfdu(cuM + cuM, S23, ev3);  // (cuM ev3 - k2) + (cuM ev3 - k3)
+            const double p1_s = (G == 1) ? pend : dpp_quad_pl<(G == 4) ? 0x90 : 0xA0>(p1);
+            const double pabove = csub ? p1_s : pend;
+            double* dp = a.dJdu + (size_t)(2 * i + 2) * B + bx;
+            *dp = pabove + p4;   // column 2i+2
+            *(dp - B) = p23;     // column 2i+1
+            pend = (G == 1) ? p1 : dpp_quad_pl<(G == 4) ? 0xFF : 0xF5>(p1);
+            ucar = (G == 1) ? c.uA : dpp_quad_pl<(G == 4) ? 0xFF : 0xF5>(c.uA);
+          }
         }
       }
       tc += PL_T() - t1;
@@ -804,7 +844,7 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
     }
 #endif
     (void)tb; (void)tc;
-    if (OUT_DJDU) *dp = group_sum_pl<G>(pend);  // left end point :101-102
+    if (OUT_DJDU && csub == 0) a.dJdu[bx] = pend;  // left end point :101-102
   }
 }
 
