@@ -252,7 +252,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
             Y = __builtin_fma(c.h, F3, y);
             w[(D + s) * SS] = double2{Y3, Y};              // (Y3, Y4) - m/2
             const double F4 = P::row_f_shifted(Y, cB);
-            y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
+            y = __builtin_fma(c.h6, F4, __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)), y));  // (F4 joins last:
+            // one dependent operation after it instead of two)
             cprev = cB;
           }
         }
@@ -393,7 +394,8 @@ __global__ __launch_bounds__(192) void k_forward_pl(const FwdArgsPL a) {
           Y = __builtin_fma(c.h, F3, y);
           w[(D + s) * SS] = double2{Y3, Y};              // (Y3, Y4) - m/2
           const double F4 = P::row_f_shifted(Y, cB);
-          y = __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)) + F4, y);
+          y = __builtin_fma(c.h6, F4, __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)), y));  // (F4 joins last:
+            // one dependent operation after it instead of two)
           cprev = cB;
           uprev = c.uB;
         }
@@ -967,7 +969,7 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
         const double k3 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
         L = __builtin_fma(-c.h, k3, l);
         const double k4 = -P::row_dfdx(c.xA, L, 2.0 * c.eA, rp);
-        l = __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)) + k4, l);
+        l = __builtin_fma(-c.h6, k4, __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)), l));  // (k4 last)
         ls -= colB;
         if (!fz) *ls = l;
         xB = c.xA;
@@ -1172,7 +1174,7 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
       const double k3 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
       L = __builtin_fma(-c.h, k3, l);
       const double k4 = -P::row_dfdx(c.xA, L, 2.0 * c.eA, rp);
-      l = __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)) + k4, l);
+      l = __builtin_fma(-c.h6, k4, __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)), l));  // (k4 last)
       ls -= colB;
       if (!fz) *ls = l;
       xB = c.xA;
