@@ -934,6 +934,7 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
   double* ls = a.lam + (size_t)N * G * B + (size_t)r * B + b;
   double l = 0.0;                                           // lam0 = 0*x0   compute_x_lam.m:4
   double xB = a.x[((size_t)N * a.ldx + r) * B + b];         // x(t_N)
+  double eB = 2.0 * a.REC[(size_t)(N - 1) * RS + 6];           // 2 e^{-r t_N}
   if (!fz) *ls = 0.0;
   for (int k = 0; k <= nb; ++k) {
     lds_barrier();
@@ -941,16 +942,15 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
       const double* slot = &inp[k % NSLOT][0];
       const double* xs = slot + XOFF + r * TPW + tl;
       const double* ms = slot + MOFF + r * TPW + tl;
-      struct In { double h, hh, h6, eA, eM, eB, xA, xM; };
+      struct In { double h, hh, h6, eA, eM, xA, xM; };
       auto fetch = [&](int s) OCS_INLINE {  // s-th step processed = local ascending index D-1-s
         const int q = D - 1 - s;
         In v;
         v.h = slot[RS * q];
         v.hh = slot[RS * q + 1];
         v.h6 = slot[RS * q + 2];
-        v.eA = slot[RS * q + 4];
-        v.eM = slot[RS * q + 5];
-        v.eB = slot[RS * q + 6];
+        v.eA = slot[RS * q + rec_sc_offset(1) + 6];  // 2 e^{-r t} at the left node and at the midpoint (step constants); the
+        v.eM = slot[RS * q + rec_sc_offset(1) + 7];  // right node's is the left node's of the step processed before
         v.xA = xs[q * 64];
         v.xM = ms[q * 64];
         return v;
@@ -962,17 +962,18 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
         if (s + 1 < D) nxt = fetch(s + 1);
         __builtin_amdgcn_sched_barrier(0);
         // adjointRHS(t, x, lam) = -dFdx_times_vec(t, [x;0], u, [lam;1])(row r); ev = 2 e^{-rt} * 1
-        const double k1 = -P::row_dfdx(xB, l, 2.0 * c.eB, rp);
+        const double k1 = -P::row_dfdx(xB, l, eB, rp);
         double L = __builtin_fma(-c.hh, k1, l);
-        const double k2 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+        const double k2 = -P::row_dfdx(c.xM, L, c.eM, rp);
         L = __builtin_fma(-c.hh, k2, l);
-        const double k3 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+        const double k3 = -P::row_dfdx(c.xM, L, c.eM, rp);
         L = __builtin_fma(-c.h, k3, l);
-        const double k4 = -P::row_dfdx(c.xA, L, 2.0 * c.eA, rp);
+        const double k4 = -P::row_dfdx(c.xA, L, c.eA, rp);
         l = __builtin_fma(-c.h6, k4, __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)), l));  // (k4 last)
         ls -= colB;
         if (!fz) *ls = l;
         xB = c.xA;
+        eB = c.eA;
       }
     }
   }
@@ -1139,6 +1140,7 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
   double* ls = a.lam + (size_t)N * G * B + (size_t)r * B + b;
   double l = 0.0;
   double xB = xN;
+  double eB = 2.0 * a.REC[(size_t)(N - 1) * RS + 6];  // 2 e^{-r t_N}
   if (!fz) *ls = 0.0;
   for (int k = 0; k <= nb + 1; ++k) {
     lds_barrier();
@@ -1147,16 +1149,15 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
     const double* slot = &inp[j % NSLOT][0];
     const double* xs = slot + XOFF + r * TPW + tl;
     const double* ms = &xm[j & 1][0][lane];
-    struct In { double h, hh, h6, eA, eM, eB, xA, xM; };
+    struct In { double h, hh, h6, eA, eM, xA, xM; };
     auto fetch = [&](int s) OCS_INLINE {
       const int q = D - 1 - s;
       In v;
       v.h = slot[RS * q];
       v.hh = slot[RS * q + 1];
       v.h6 = slot[RS * q + 2];
-      v.eA = slot[RS * q + 4];
-      v.eM = slot[RS * q + 5];
-      v.eB = slot[RS * q + 6];
+      v.eA = slot[RS * q + rec_sc_offset(1) + 6];  // 2 e^{-r t} at the left node and at the midpoint (step constants); the
+      v.eM = slot[RS * q + rec_sc_offset(1) + 7];  // right node's is the left node's of the step processed before
       v.xA = xs[q * 64];
       v.xM = ms[q * 64];
       return v;
@@ -1167,17 +1168,18 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
       const In c = nxt;
       if (s + 1 < D) nxt = fetch(s + 1);
       __builtin_amdgcn_sched_barrier(0);
-      const double k1 = -P::row_dfdx(xB, l, 2.0 * c.eB, rp);
+      const double k1 = -P::row_dfdx(xB, l, eB, rp);
       double L = __builtin_fma(-c.hh, k1, l);
-      const double k2 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+      const double k2 = -P::row_dfdx(c.xM, L, c.eM, rp);
       L = __builtin_fma(-c.hh, k2, l);
-      const double k3 = -P::row_dfdx(c.xM, L, 2.0 * c.eM, rp);
+      const double k3 = -P::row_dfdx(c.xM, L, c.eM, rp);
       L = __builtin_fma(-c.h, k3, l);
-      const double k4 = -P::row_dfdx(c.xA, L, 2.0 * c.eA, rp);
+      const double k4 = -P::row_dfdx(c.xA, L, c.eA, rp);
       l = __builtin_fma(-c.h6, k4, __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)), l));  // (k4 last)
       ls -= colB;
       if (!fz) *ls = l;
       xB = c.xA;
+      eB = c.eA;
     }
   }
 }

@@ -85,7 +85,7 @@ struct LogisticK {
   }
   // Per-step constants that depend on the grid only (uniform over the batch); computed once into the
   // record table so that the wave-specialised kernels need not recompute them per lane and step.
-  static constexpr int NSC = 6;
+  static constexpr int NSC = 8;
   __device__ static inline void step_consts(double h6, double h3, const double* tcA, const double* tcM,
                                             const double* tcB, double* sc) {
     sc[0] = (2.0 * tcB[0]) * h6;  // E4:  2 e^{-r t} * (h/6): cost-row factor of dFdx_times_vec at stage 4
@@ -94,6 +94,8 @@ struct LogisticK {
     sc[3] = h6 * tcA[0];          // W_A: RK4 quadrature weights of the objective integrand
     sc[4] = 2.0 * (h6 * tcM[0]);  // W_M
     sc[5] = h6 * tcB[0];          // W_B
+    sc[6] = 2.0 * tcA[0];         // cost-row factor of the continuous adjoint right-hand side at the left node
+    sc[7] = 2.0 * tcM[0];         //   ... and at the midpoint (costate pass of the sweep; the right node is the next step's left)
   }
 
   // ---- row-separable form (row-split mapping, ocs_rowsplit_kernels.hip) --------------------
