@@ -934,7 +934,8 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
   double* ls = a.lam + (size_t)N * G * B + (size_t)r * B + b;
   double l = 0.0;                                           // lam0 = 0*x0   compute_x_lam.m:4
   double xB = a.x[((size_t)N * a.ldx + r) * B + b];         // x(t_N)
-  double eB = 2.0 * a.REC[(size_t)(N - 1) * RS + 6];           // 2 e^{-r t_N}
+  double aB, bB;                                             // at x(t_N), with 2 e^{-r t_N}
+  P::row_dfdx_pre(xB, 2.0 * a.REC[(size_t)(N - 1) * RS + 6], rp, aB, bB);
   if (!fz) *ls = 0.0;
   for (int k = 0; k <= nb; ++k) {
     lds_barrier();
@@ -962,18 +963,23 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
         if (s + 1 < D) nxt = fetch(s + 1);
         __builtin_amdgcn_sched_barrier(0);
         // adjointRHS(t, x, lam) = -dFdx_times_vec(t, [x;0], u, [lam;1])(row r); ev = 2 e^{-rt} * 1
-        const double k1 = -P::row_dfdx(xB, l, eB, rp);
+        // row of (dF/dy)' v in affine form a v + b (P::row_dfdx_pre); the pair of the right node is the left node's of
+        // the step processed before
+        double aM, bM, aA, bA;
+        P::row_dfdx_pre(c.xM, c.eM, rp, aM, bM);
+        P::row_dfdx_pre(c.xA, c.eA, rp, aA, bA);
+        const double k1 = -__builtin_fma(aB, l, bB);
         double L = __builtin_fma(-c.hh, k1, l);
-        const double k2 = -P::row_dfdx(c.xM, L, c.eM, rp);
+        const double k2 = -__builtin_fma(aM, L, bM);
         L = __builtin_fma(-c.hh, k2, l);
-        const double k3 = -P::row_dfdx(c.xM, L, c.eM, rp);
+        const double k3 = -__builtin_fma(aM, L, bM);
         L = __builtin_fma(-c.h, k3, l);
-        const double k4 = -P::row_dfdx(c.xA, L, c.eA, rp);
+        const double k4 = -__builtin_fma(aA, L, bA);
         l = __builtin_fma(-c.h6, k4, __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)), l));  // (k4 last)
         ls -= colB;
         if (!fz) *ls = l;
-        xB = c.xA;
-        eB = c.eA;
+        aB = aA;
+        bB = bA;
       }
     }
   }
@@ -1140,7 +1146,8 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
   double* ls = a.lam + (size_t)N * G * B + (size_t)r * B + b;
   double l = 0.0;
   double xB = xN;
-  double eB = 2.0 * a.REC[(size_t)(N - 1) * RS + 6];  // 2 e^{-r t_N}
+  double aB, bB;  // at x(t_N), with 2 e^{-r t_N}
+  P::row_dfdx_pre(xB, 2.0 * a.REC[(size_t)(N - 1) * RS + 6], rp, aB, bB);
   if (!fz) *ls = 0.0;
   for (int k = 0; k <= nb + 1; ++k) {
     lds_barrier();
@@ -1168,18 +1175,23 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
       const In c = nxt;
       if (s + 1 < D) nxt = fetch(s + 1);
       __builtin_amdgcn_sched_barrier(0);
-      const double k1 = -P::row_dfdx(xB, l, eB, rp);
+      // row of (dF/dy)' v in affine form a v + b (P::row_dfdx_pre); the pair of the right node is the left node's of
+      // the step processed before
+      double aM, bM, aA, bA;
+      P::row_dfdx_pre(c.xM, c.eM, rp, aM, bM);
+      P::row_dfdx_pre(c.xA, c.eA, rp, aA, bA);
+      const double k1 = -__builtin_fma(aB, l, bB);
       double L = __builtin_fma(-c.hh, k1, l);
-      const double k2 = -P::row_dfdx(c.xM, L, c.eM, rp);
+      const double k2 = -__builtin_fma(aM, L, bM);
       L = __builtin_fma(-c.hh, k2, l);
-      const double k3 = -P::row_dfdx(c.xM, L, c.eM, rp);
+      const double k3 = -__builtin_fma(aM, L, bM);
       L = __builtin_fma(-c.h, k3, l);
-      const double k4 = -P::row_dfdx(c.xA, L, c.eA, rp);
+      const double k4 = -__builtin_fma(aA, L, bA);
       l = __builtin_fma(-c.h6, k4, __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)), l));  // (k4 last)
       ls -= colB;
       if (!fz) *ls = l;
-      xB = c.xA;
-      eB = c.eA;
+      aB = aA;
+      bB = bA;
     }
   }
 }
