@@ -621,7 +621,14 @@ __global__ void k_fbs_advance(int batch, int sweep, int nparts, const double* __
     (void)anyvalid;
     double mx = -1.0;  // max over the valid (non-NaN) weighted changes, NaN if there is none (:108)
     int q = 0;
-    for (; q + 8 <= nparts; q += 8) {  // eight independent loads in flight
+    for (; q + 32 <= nparts; q += 32) {  // 32 independent loads in flight: the kernel is a few waves of pure latency
+      double m[32];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) m[j] = metric[(size_t)(q + j) * ld + b];
+#pragma unroll
+      for (int j = 0; j < 32; ++j) mx = fmax(mx, m[j]);
+    }
+    for (; q + 8 <= nparts; q += 8) {
       double m[8];
 #pragma unroll
       for (int j = 0; j < 8; ++j) m[j] = metric[(size_t)(q + j) * ld + b];

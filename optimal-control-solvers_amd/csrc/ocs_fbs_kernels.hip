@@ -132,7 +132,7 @@ int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* 
 int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
                        double* maxChange, int* nactive, hipStream_t s, int ldb, const int* gate) {
-  k_fbs_advance<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, sweep, nparts, metric, anyvalid, usel, status,
+  k_fbs_advance<<<dim3((batch + 63) / 64), dim3(64), 0, s>>>(batch, sweep, nparts, metric, anyvalid, usel, status,
                                                                  maxChange, nactive, ldb, gate);
   return hip_rc3(hipGetLastError());
 }
