@@ -1024,15 +1024,24 @@ __device__ static inline double pchip_end_pl(double h0, double h1, double del0, 
   return d;
 }
 
-// one helper wave of k_costate_plx: the pchip midpoints of intervals q0 .. q0+RL-1 (ascending positions) of every block
-template <class C_, int RL>
+// one helper wave of k_costate_plx: the pchip midpoints of intervals q0 .. q0+RL-1 (ascending positions) of every block;
+// ST: this wave also stores the costate values the recursion wave leaves in LDS (lr), so that the recursion wave
+// carries neither the store pointer nor the exec masking of frozen instances
+template <class C_, int RL, bool ST>
 __device__ static inline void costate_midpoints(const double (*inp)[C_::SLOT], double (*xm)[C_::D][64], int q0, int N,
-                                                int r, int tl, int lane, double xN) {
+                                                int r, int tl, int lane, double xN, const double (*lr)[C_::D][64],
+                                                double* lamp, size_t colB, bool fz) {
   constexpr int D = C_::D, TPW = C_::TPW, NSLOT = C_::NSLOT;
   constexpr int POFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::PR_DBL;
   const int nb = N / D;
-  for (int k = 0; k <= nb + 1; ++k) {
+  for (int k = 0; k <= nb + 2; ++k) {
     lds_barrier();
+    if (ST && k >= 3 && !fz) {  // lam of the block the recursion wave finished in the interval before: its stores
+      const int jl = k - 3;
+      double* lp = lamp + (size_t)(N - 1 - jl * D) * colB;
+#pragma unroll
+      for (int s = 0; s < D; ++s) lp[-(ptrdiff_t)((size_t)s * colB)] = lr[jl & 1][s][lane];
+    }
     const int j = k - 1;
     if (j < 0 || j >= nb) continue;
     const double* slot = &inp[0][0] + C_::SLOT * (j % NSLOT);
@@ -1090,6 +1099,7 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
   const CostateArgsPL& a = aa.c;
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];
   __shared__ __attribute__((aligned(16))) double xm[2][D][64];
+  __shared__ __attribute__((aligned(16))) double lr[2][D][64];  // L -> H2: lam of a block, for the stores
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
@@ -1112,7 +1122,7 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
       }
     };
     for (int j = 0; j < Q && j < nb; ++j) issue(j);
-    for (int k = 0; k <= nb + 1; ++k) {
+    for (int k = 0; k <= nb + 2; ++k) {
       if (k < nb) {
         const int behind = (nb - 1 - k) < (Q - 1) ? (nb - 1 - k) : (Q - 1);
         wait_blocks<C_::LPB>(behind);
@@ -1129,11 +1139,12 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
     // ---------------- H0, H1, H2: pchip midpoints of intervals 0-2, 3-5, 6-7 of every block ----------------
     // (waves 1, 2, 4: one per SIMD beside the recursion wave's; two helpers on one SIMD were the bottleneck)
     if (wave == 1)
-      costate_midpoints<C_, 3>(inp, xm, 0, N, r, tl, lane, xN);
+      costate_midpoints<C_, 3, false>(inp, xm, 0, N, r, tl, lane, xN, lr, nullptr, 0, true);
     else if (wave == 2)
-      costate_midpoints<C_, 3>(inp, xm, 3, N, r, tl, lane, xN);
-    else
-      costate_midpoints<C_, 2>(inp, xm, 6, N, r, tl, lane, xN);
+      costate_midpoints<C_, 3, false>(inp, xm, 3, N, r, tl, lane, xN, lr, nullptr, 0, true);
+    else  // the helper with the shortest run also stores lam
+      costate_midpoints<C_, 2, true>(inp, xm, 6, N, r, tl, lane, xN, lr, a.lam + (size_t)r * B + b, (size_t)G * B,
+                                     FRZ && a.frozen[b] != 0);
     return;
   }
   // ---------------- L: costate recursion ----------------
@@ -1143,16 +1154,16 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
   }, r);
   const bool fz = FRZ && a.frozen[b] != 0;
   const size_t colB = (size_t)G * B;
-  double* ls = a.lam + (size_t)N * G * B + (size_t)r * B + b;
   double l = 0.0;
   double xB = xN;
   double aB, bB;  // at x(t_N), with 2 e^{-r t_N}
   P::row_dfdx_pre(xB, 2.0 * a.REC[(size_t)(N - 1) * RS + 6], rp, aB, bB);
-  if (!fz) *ls = 0.0;
-  for (int k = 0; k <= nb + 1; ++k) {
+  if (!fz) a.lam[(size_t)N * colB + (size_t)r * B + b] = 0.0;
+  for (int k = 0; k <= nb + 2; ++k) {
     lds_barrier();
     const int j = k - 2;
-    if (j < 0) continue;
+    if (j < 0 || j >= nb) continue;
+    double* lw = &lr[j & 1][0][lane];
     const double* slot = &inp[j % NSLOT][0];
     const double* xs = slot + XOFF + r * TPW + tl;
     const double* ms = &xm[j & 1][0][lane];
@@ -1188,8 +1199,7 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
       L = __builtin_fma(-c.h, k3, l);
       const double k4 = -__builtin_fma(aA, L, bA);
       l = __builtin_fma(-c.h6, k4, __builtin_fma(-c.h6, __builtin_fma(2.0, k3, __builtin_fma(2.0, k2, k1)), l));  // (k4 last)
-      ls -= colB;
-      if (!fz) *ls = l;
+      lw[s * 64] = l;  // stored by the helper wave
       aB = aA;
       bB = bA;
     }
