@@ -326,7 +326,8 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     HIP_TRY(hipMemcpyAsync(f->uerr.p, u0err, sizeof(double) * uerrN, hipMemcpyDeviceToDevice, s));
   } else {       // u0 = ControlBounds(:,1)*ones(1,length(t))  :23
     LAUNCH_TRY(launch_fill_rows(nT, nC, batch, p->d_lb.d(), f->ugrid.d(), s));
-    LAUNCH_TRY(launch_fill_rows(nE, nC, batch, p->d_lb.d(), f->uerr.d(), s));
+    // (with the change measured on the grid nodes the separate error-point samples are never read)
+    if (!fusedup) LAUNCH_TRY(launch_fill_rows(nE, nC, batch, p->d_lb.d(), f->uerr.d(), s));
   }
   const ProblemDesc pd = describe(p);
   const GridDesc gd = describe(g);
