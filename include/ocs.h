@@ -102,12 +102,16 @@ int ocs_problem_dFdu_times_vec(ocs_problem p, int k, const double *t, const doub
 int ocs_rk4_create(ocs_integrator *out, const double *tspan, int npts);
 int ocs_integrator_destroy(ocs_integrator g);
 int ocs_integrator_nsteps(ocs_integrator g, int *nsteps); /* obj.nSTEPS */
-/* Thread mapping of the serial RK4 kernels (no counterpart in the reference): 0 automatic,
- * 1 lane-per-trajectory, 2 row-split (one state row per lane; row-separable problems only, returns
- * OCS_ERR_UNSUPPORTED at the next compute call otherwise).  Results agree to fp64 round-off. */
+/* Thread mapping of the RK4 kernels (no counterpart in the reference): 0 automatic,
+ * 1 lane-per-trajectory, 2 row-split (one state row per lane), 3 wave-specialised pipeline,
+ * 4 adjoint pass as a scan over time (compute_states then runs the pipeline mapping).  2-4 are for
+ * row-separable problems only (OCS_ERR_UNSUPPORTED at the next compute call otherwise).
+ * Results agree to fp64 round-off. */
 #define OCS_MAPPING_AUTO 0
 #define OCS_MAPPING_LANE 1
 #define OCS_MAPPING_ROWSPLIT 2
+#define OCS_MAPPING_PIPELINE 3
+#define OCS_MAPPING_SCAN 4
 int ocs_integrator_set_mapping(ocs_integrator g, int mapping);
 int ocs_integrator_t(ocs_integrator g, double *t);        /* obj.t, 2N+1 values */
 int ocs_integrator_h(ocs_integrator g, double *h);        /* obj.h, N values    */

@@ -231,7 +231,7 @@ int ocs_integrator_destroy(ocs_integrator g) {
   g->d_ustar.release();
   g->d_lam2.release();
   if (g->stream) (void)hipStreamDestroy(g->stream);
-  DevBuf* bufs[] = {&g->d_HT, &g->d_T, &g->d_TC, &g->d_TU, &g->d_REC, &g->d_x0, &g->d_u, &g->d_x, &g->d_J,
+  DevBuf* bufs[] = {&g->d_HT, &g->d_T, &g->d_TC, &g->d_TU, &g->d_REC, &g->d_RECS, &g->d_split, &g->d_x0, &g->d_u, &g->d_x, &g->d_J,
                     &g->d_lam, &g->d_dJdu, &g->d_lamT, &g->d_stage, &g->d_ck};
   for (DevBuf* b : bufs) b->release();
   delete g;
@@ -239,7 +239,7 @@ int ocs_integrator_destroy(ocs_integrator g) {
 }
 int ocs_integrator_set_mapping(ocs_integrator g, int mapping) {
   if (!g) return fail(OCS_ERR_INVALID, "null integrator");
-  if (mapping < MAP_AUTO || mapping > MAP_PIPELINE) return fail(OCS_ERR_INVALID, "mapping must be 0..3");
+  if (mapping < MAP_AUTO || mapping > MAP_SCAN) return fail(OCS_ERR_INVALID, "mapping must be 0..4");
   g->mapping = mapping;
   if (g->leg2) g->leg2->mapping = mapping;
   return OCS_OK;
@@ -312,6 +312,10 @@ int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const d
   BwdOpts o;
   o.mapping = g->mapping;
   o.lam0 = g->want_lam0;
+  if (!lam) {
+    OCS_TRY(g->d_split.ensure(sizeof(double) * (size_t)(p->nS + 1) * batch));
+    o.split_scratch = g->d_split.d();
+  }
   if (g->kind == 1) {
     // RK4InfiniteIntegrator.m:27-30: lam2 = leg2.adjoints(uStar); [lam,dJdu] = leg1.adjoints(u, lam2(:,1))
     if (lamT) return fail(OCS_ERR_INVALID, "RK4InfiniteIntegrator.compute_adjoints takes no lamT");

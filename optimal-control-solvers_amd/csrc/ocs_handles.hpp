@@ -126,7 +126,7 @@ struct ocs_integrator_s {
   DevBuf d_ustar, d_lam2;             // device uStar [nC]; lam2(:,1) [nAug][B]
   int N = 0;
   std::vector<double> tspan, t, h;
-  DevBuf d_HT, d_T, d_TC, d_TU, d_REC;
+  DevBuf d_HT, d_T, d_TC, d_TU, d_REC, d_RECS, d_split;
   bool grid_uploaded = false;
   unsigned long long tc_version = 0;  // version of the problem TC was built for
   const ocs_problem_s* tc_prob = nullptr;
@@ -203,6 +203,7 @@ inline GridDesc describe(const ocs_integrator_s* g) {
   d.TC = g->d_TC.d();
   d.TU = g->d_TU.d();
   d.REC = g->d_REC.d() ? g->d_REC.d() + (size_t)rec_pad_host() * g->rec_stride : nullptr;
+  d.RECS = g->d_RECS.d() ? g->d_RECS.d() + scan_recs_front() : nullptr;
   return d;
 }
 
@@ -221,6 +222,10 @@ inline int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStr
     g->rec_stride = rec_stride_host(ntc);
     OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)(g->N + 2 * rec_pad_host()) * g->rec_stride));
     LAUNCH_TRY(launch_tcoef(describe(p), describe(g), s));
+    if (scan_supported(p->functor, p->nS, p->nC)) {
+      OCS_TRY(g->d_RECS.ensure(sizeof(double) * scan_recs_doubles(g->N)));
+      LAUNCH_TRY(launch_build_recs(g->N, g->rec_stride, rec_sc_offset_host(ntc), describe(g).REC, g->d_RECS.d(), s));
+    }
     g->tc_prob = p;
     g->tc_version = p->version;
   }

@@ -29,6 +29,7 @@ struct GridDesc {
   double* TC;         // device: [2N+1][NTC] time coefficients of the bound problem (F side)
   double* TU;         // device: [2N+1][NTU] time coefficients of its ControlChar
   double* REC;        // device: [N][rec_stride(NTC)] per-step records {h,h/2,h/6,h/3,tcA,tcM,tcB}
+  double* RECS = nullptr;  // device: compact zero-padded records of the scan kernels (record of step 0), or nullptr
 };
 
 // Device-native layouts (batch-minor): x0 [nS][B], u [2N+1][nC][B], x [N+1][nAug][B],
@@ -36,7 +37,19 @@ struct GridDesc {
 int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s);
 // mapping of the serial RK4 kernels: lane-per-trajectory (ocs_kernels.hip) or row-split
 // (ocs_rowsplit_kernels.hip, row-separable problems only)
-enum Mapping : int { MAP_AUTO = 0, MAP_LANE = 1, MAP_ROWSPLIT = 2, MAP_PIPELINE = 3 };
+enum Mapping : int { MAP_AUTO = 0, MAP_LANE = 1, MAP_ROWSPLIT = 2, MAP_PIPELINE = 3, MAP_SCAN = 4 };
+// adjoint pass as a scan over time (ocs_scan_kernels.hip): row-separable problems, any N, any batch
+bool scan_supported(Functor f, int nS, int nC);
+// N a multiple of scan_chunk_steps(); pend0 as for launch_backward_pl
+int scan_chunk_steps();
+int launch_backward_scan(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                         const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
+                         hipStream_t s);
+// the scan kernels' record table: scan_recs_doubles(N) doubles at RECS_base, built from REC (stride rs, step
+// constants at sco); GridDesc::RECS = RECS_base + scan_recs_front()
+size_t scan_recs_doubles(int N);
+size_t scan_recs_front();
+int launch_build_recs(int N, int rs, int sco, const double* REC, double* RECS_base, hipStream_t s);
 bool pipeline_supported(Functor f, int nS, int nC);
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward);  // nSTEPS multiple of the block, batch of the tile
 int pipeline_block_steps();  // the pipeline kernels take whole blocks of this many steps
@@ -92,6 +105,7 @@ struct BwdOpts {
   int mapping = MAP_AUTO;
   bool uconst = false;
   double* lam0 = nullptr;       // [nAug][B]: lam(:,1)
+  double* split_scratch = nullptr;  // [nAug][B]: hand-over column of a split pass when no lam array is requested
 };
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s);
@@ -192,6 +206,7 @@ bool functor_supported(Functor f, int nS, int nC);
 int functor_ntc(Functor f, int nS);
 int functor_ntu(Functor f, int nS);
 int rec_stride_host(int ntc);
+int rec_sc_offset_host(int ntc);
 int rec_pad_host();
 unsigned functor_tc_param_mask(Functor f, int nS);
 

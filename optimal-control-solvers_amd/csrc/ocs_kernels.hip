@@ -122,6 +122,7 @@ int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s) {
   return hip_rc(hipGetLastError());
 }
 int rec_stride_host(int ntc) { return rec_stride(ntc); }
+int rec_sc_offset_host(int ntc) { return rec_sc_offset(ntc); }
 int rec_pad_host() { return kRecPad; }
 
 constexpr int kChunk = 4;
@@ -169,6 +170,13 @@ static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested,
   return MAP_LANE;
 }
 
+// Scan against the serial mappings: the scan does ~2x the arithmetic of a serial adjoint step but has no
+// dependent chain over time; it wins wherever the serial kernels are latency-bound (every batch measured so far).
+static bool scan_pays(int nS, int N, int batch) {
+  (void)nS; (void)batch;
+  return N >= 8;
+}
+
 bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
   if (p.functor == Functor::LQ) return false;
   return choose_mapping(p, g.N, batch, MAP_AUTO, true, false, true) == MAP_PIPELINE &&
@@ -180,7 +188,8 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
   if (o.gate && (o.mapping != MAP_AUTO || o.uconst || o.Jadd || !forward_gate_supported(p, g, batch))) return -1;
   if (p.functor == Functor::LQ) return launch_forward_lq(p, g, batch, x0, u, x, J, o, s);
   const bool plain = !o.uconst && !o.Jadd;
-  int map = choose_mapping(p, g.N, batch, o.mapping, plain, false, x != nullptr);
+  // (MAP_SCAN names the adjoint kernel; the state pass of such an integrator is chosen automatically)
+  int map = choose_mapping(p, g.N, batch, o.mapping == MAP_SCAN ? MAP_AUTO : o.mapping, plain, false, x != nullptr);
   if (map == MAP_ROWSPLIT && (o.frozen || o.ld) && o.mapping == MAP_AUTO) map = MAP_LANE;  // not in that kernel
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, false) : 0;
@@ -231,7 +240,31 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
                     const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
   if (p.functor == Functor::LQ) return launch_backward_lq(p, g, batch, xck, u, lamT, lam, dJdu, o, s);
   const bool plain = !o.uconst;
-  const int map = choose_mapping(p, g.N, batch, o.mapping, plain, true, lam != nullptr);
+  int map = choose_mapping(p, g.N, batch, o.mapping, plain, true, lam != nullptr);
+  // the adjoint pass as a scan over time: whenever the problem is row-separable (any N, any batch); the serial
+  // mappings remain selectable
+  // The scan takes whole chunks of L steps; other step counts are split as for the pipeline mapping: steps N1..N-1
+  // first on the lane kernel (which hands lam(:, N1) and the k1 half of column 2 N1 over through the output arrays),
+  // so a split pass needs the lam array.
+  const int Ls = scan_chunk_steps(), Ns = (g.N / Ls) * Ls;
+  const bool scan_ok = plain && g.RECS && scan_supported(p.functor, p.nS, p.nC) && Ns >= Ls && (Ns == g.N || lam || o.split_scratch);
+  if (o.mapping == MAP_AUTO && scan_ok && scan_pays(p.nS, g.N, batch)) map = MAP_SCAN;
+  if (map == MAP_SCAN) {
+    if (!scan_ok) return -1;
+    if (Ns == g.N) return launch_backward_scan(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, nullptr, s);
+    const size_t col = (size_t)(p.nS + 1) * batch, ucol = (size_t)p.nC * batch;
+    double* lamb = lam ? lam + (size_t)Ns * col : o.split_scratch;   // lam(:, Ns): in the output array, or as lam0
+    double* db = dJdu ? dJdu + (size_t)(2 * Ns) * ucol : nullptr;
+    const BwdArgs a{g.N - Ns, batch, g.REC + (size_t)Ns * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
+                    p.pmask, xck + (size_t)Ns * col, u + (size_t)(2 * Ns) * ucol, lamT, lam ? lamb : nullptr, db,
+                    lam ? nullptr : lamb};
+    OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, false, s));
+    int rc = hip_rc(hipGetLastError());
+    if (rc) return rc;
+    GridDesc g1 = g;
+    g1.N = Ns;
+    return launch_backward_scan(p, g1, batch, xck, u, lamb, lam, dJdu, o.lam0, db, s);
+  }
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, true) : 0;
     if (N1 == 0 || (N1 < g.N && !lam)) return -1;  // the split hands lam(:, N1) over through memory

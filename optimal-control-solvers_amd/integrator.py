@@ -65,7 +65,7 @@ class RK4Integrator(Integrator):
 
     def set_mapping(self, mapping):
         """Thread mapping of the RK4 kernels: "auto", "lane" (lane per trajectory) or "rowsplit"."""
-        code = mapping if isinstance(mapping, int) else {"auto": 0, "lane": 1, "rowsplit": 2, "pipeline": 3}[mapping]
+        code = mapping if isinstance(mapping, int) else {"auto": 0, "lane": 1, "rowsplit": 2, "pipeline": 3, "scan": 4}[mapping]
         check(lib.ocs_integrator_set_mapping(self._h, code))
         return self
 

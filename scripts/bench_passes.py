@@ -1,5 +1,7 @@
+"""Times compute_states / compute_adjoints (device entry points) per mapping and batch.
+  MAPPING=auto|lane|rowsplit|pipeline|scan BATCHES=4096,16384 NSTEPS=1000 python scripts/bench_passes.py"""
 import os, sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import __graft_entry__ as g
 ocs = g.load_package()
 dev = torch.device('cuda:0')

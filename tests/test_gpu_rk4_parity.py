@@ -92,7 +92,7 @@ def test_states_and_adjoints_match_oracle(ocs, oracle, nS, N, batch, T):
                                           (4, 37, 1, 2.0), (2, 1000, 40, 10.0), (4, 8, 17, 0.4), (4, 16, 64, 0.8), (4, 48, 32, 2.0), (2, 8, 32, 0.4), (2, 40, 96, 2.0), (4, 1008, 16, 10.0),
                                           (2, 17, 33, 0.8), (4, 24, 3, 1.0), (4, 1003, 16, 10.0), (2, 17, 32, 0.8),
                                           (4, 12, 32, 0.6), (2, 15, 64, 0.7), (4, 7, 16, 0.3)])
-@pytest.mark.parametrize("mapping", ["lane", "rowsplit", "pipeline"])
+@pytest.mark.parametrize("mapping", ["lane", "rowsplit", "pipeline", "scan"])
 def test_both_mappings_match_oracle(ocs, oracle, nS, N, batch, T, mapping):
     # the row-split kernels (one state row per lane) must give the same answers as lane-per-trajectory,
     # including explicit lamT, lam-only / dJdu-only variants and partially filled last waves
@@ -111,6 +111,11 @@ def test_both_mappings_match_oracle(ocs, oracle, nS, N, batch, T, mapping):
         assert e.value.code == -6
         return
     x, J = g.compute_states(pg, x0, u)
+    if mapping == "scan" and N < 4:
+        with pytest.raises(ocs.OcsError) as e:
+            g.compute_adjoints(pg, u)
+        assert e.value.code == -6
+        return
     lam, dJdu = g.compute_adjoints(pg, u)
     ref = oracle.batch_states_adjoints(po, tspan, x0, u)
     assert relerr(x, ref["x"]) < RTOL and relerr(J, ref["J"]) < RTOL
@@ -271,6 +276,59 @@ def test_full_size_properties_bl2(ocs, oracle):
     b = g.compute_adjoints(pg, u, l2, nargout=1)
     c = g.compute_adjoints(pg, u, l1 + l2, nargout=1)
     assert relerr(a + b, c) < 1e-11
+
+
+@pytest.mark.parametrize("nS,N,batch,T", [(1, 1, 3, 0.05), (1, 47, 70, 2.0), (1, 48, 64, 2.0), (1, 49, 129, 2.0),
+                                          (2, 95, 33, 3.0), (2, 96, 64, 3.0), (4, 97, 17, 3.0), (4, 500, 48, 10.0),
+                                          (1, 1000, 64, 10.0), (4, 2, 16, 0.1), (2, 4, 5, 0.2), (4, 5, 1, 0.2)])
+def test_adjoint_scan_over_time(ocs, oracle, nS, N, batch, T):
+    # the adjoint pass as a scan over time (row-separable problems): step counts around the superblock length
+    # (identity-padded last superblock), ragged batches, explicit lamT, the lam-only and dJdu-only variants, lam0,
+    # and a non-uniform grid
+    import torch
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    tspan, x0, u = _inputs(oracle, nS, N, batch, seed=700 + nS + N, T=T)
+    if N >= 5:
+        tspan = np.sort(np.concatenate([[0.0, T], np.random.default_rng(N).uniform(0, T, N - 1)]))
+    pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    g = ocs.RK4Integrator(tspan).set_mapping("scan")
+    x, J = g.compute_states(pg, x0, u)
+    if N < 4:
+        # the scan takes whole chunks of 4 steps (a remainder goes to the lane kernel, which hands over the boundary
+        # column); fewer than 4 steps are refused when forced (automatic selection falls back), never mis-computed
+        with pytest.raises(ocs.OcsError) as e:
+            g.compute_adjoints(pg, u)
+        assert e.value.code == -6
+        g = ocs.RK4Integrator(tspan)
+        g.compute_states(pg, x0, u)
+    lam, dJdu = g.compute_adjoints(pg, u)
+    ref = oracle.batch_states_adjoints(po, tspan, x0, u)
+    assert relerr(x, ref["x"]) < RTOL and relerr(J, ref["J"]) < RTOL
+    assert relerr(lam, ref["lam"]) < RTOL and relerr(dJdu, ref["dJdu"]) < RTOL
+    assert np.all(lam[-1] == 1.0) and np.all(lam[:nS, -1, :] == 0.0)
+    lamT = np.random.default_rng(3).normal(size=(nS + 1, batch))
+    lam2, d2 = g.compute_adjoints(pg, u, lamT)
+    go = oracle.RK4Integrator(tspan)
+    for b in sorted({0, batch // 2, batch - 1}):
+        go.compute_states(po, x0[:, b], u[:, :, b])
+        lo, do = go.compute_adjoints(po, u[:, :, b], lamT[:, b])
+        assert relerr(lam2[:, :, b], lo) < RTOL and relerr(d2[:, :, b], do) < RTOL
+    if N % 4:
+        return
+    # device entry points: lam only, dJdu only (same bits as the combined pass)
+    dev = torch.device("cuda:0")
+    x0d = torch.tensor(np.ascontiguousarray(x0), device=dev)
+    ud = torch.tensor(np.ascontiguousarray(np.transpose(u, (1, 0, 2))), device=dev)
+    xd = torch.empty((N + 1, nS + 1, batch), dtype=torch.float64, device=dev)
+    g.compute_states_dev(pg, x0d, ud, xd)
+    lamd, dd = torch.empty_like(xd), torch.empty_like(ud)
+    g.compute_adjoints_dev(pg, ud, None, lamd, dd)
+    lam_only, d_only = torch.empty_like(xd), torch.empty_like(ud)
+    g.compute_adjoints_dev(pg, ud, None, lam_only, None)
+    g.compute_adjoints_dev(pg, ud, None, None, d_only)
+    torch.cuda.synchronize()
+    assert torch.equal(lamd, lam_only) and torch.equal(dd, d_only)
+    assert relerr(np.transpose(lamd.cpu().numpy(), (1, 0, 2)), ref["lam"]) < RTOL
 
 
 @pytest.mark.parametrize("N,batch,T", [(1000, 64, 10.0), (24, 128, 1.0), (37, 64, 1.5), (8, 192, 0.4)])
