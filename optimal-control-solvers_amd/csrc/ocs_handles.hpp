@@ -119,6 +119,7 @@ struct ocs_integrator_s {
   using DevBuf = ocs::DevBuf;
   ocs_fbs_state* fbs = nullptr;
   int rec_stride = 8;  // doubles per step record of the bound problem
+  bool uniform = false;  // all steps of the grid have the same size
   int mapping = 0;  // ocs::Mapping requested through ocs_integrator_set_mapping (0 = automatic)
   int kind = 0;  // 0 RK4Integrator, 1 RK4InfiniteIntegrator (then `leg2` and `ustar` are set)
   ocs_integrator_s* leg2 = nullptr;   // integrator2 of RK4InfiniteIntegrator.m:13-14
@@ -182,6 +183,8 @@ inline int upload_grid(ocs_integrator_s* g) {
     HT[4 * i + 2] = g->h[i] / 6;  // :50, :73
     HT[4 * i + 3] = g->h[i] / 3;  // :77
   }
+  g->uniform = true;
+  for (int i = 1; i < N; ++i) g->uniform = g->uniform && g->h[i] == g->h[0];
   OCS_TRY(g->d_HT.ensure(sizeof(double) * HT.size()));
   HIP_TRY(hipMemcpy(g->d_HT.p, HT.data(), sizeof(double) * HT.size(), hipMemcpyHostToDevice));
   OCS_TRY(g->d_T.ensure(sizeof(double) * g->t.size()));
@@ -204,6 +207,7 @@ inline GridDesc describe(const ocs_integrator_s* g) {
   d.TU = g->d_TU.d();
   d.REC = g->d_REC.d() ? g->d_REC.d() + (size_t)rec_pad_host() * g->rec_stride : nullptr;
   d.RECS = g->d_RECS.d() ? g->d_RECS.d() + scan_recs_front() : nullptr;
+  d.uniform = g->uniform;
   return d;
 }
 

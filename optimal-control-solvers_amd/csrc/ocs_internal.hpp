@@ -30,6 +30,7 @@ struct GridDesc {
   double* TU;         // device: [2N+1][NTU] time coefficients of its ControlChar
   double* REC;        // device: [N][rec_stride(NTC)] per-step records {h,h/2,h/6,h/3,tcA,tcM,tcB}
   double* RECS = nullptr;  // device: compact zero-padded records of the scan kernels (record of step 0), or nullptr
+  bool uniform = false;    // every step has the same size (bitwise): kernels may keep h, h/2, h/6, h/3 in registers
 };
 
 // Device-native layouts (batch-minor): x0 [nS][B], u [2N+1][nC][B], x [N+1][nAug][B],
@@ -65,6 +66,10 @@ int launch_costate_pl(const ProblemDesc& p, const GridDesc& g, int batch, const 
 int launch_backward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                        const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
                        hipStream_t s);
+// the same pass with a minimal recursion wave (ocs_pipeline2_kernels.hip)
+int launch_forward_p2(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
+                      double* x, double* J, const int* frozen, int ld, hipStream_t s, bool no_cost_row,
+                      const int* gate);
 int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s,
                       bool no_cost_row = false, const int* gate = nullptr);

@@ -32,6 +32,7 @@
 #include "ocs_device_common.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_problems.hpp"
+#include <cstdlib>
 #ifdef OCS_PL_STAMPS
 #include <cstdio>
 #include <vector>
@@ -630,7 +631,7 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
       if (OUT_LAM && k < nb) {
         const int itop = N - 1 - k * D;
 #pragma unroll
-        for (int s2 = 0; s2 < D; s2 += 64 / TPW) lc[(size_t)(itop - s2 - so) * colB] = lamc2;
+        for (int s2 = 0; s2 < D; s2 += 64 / TPW) __builtin_nontemporal_store(lamc2, &lc[(size_t)(itop - s2 - so) * colB]);
       }
       if (k < nb) {
         const double* slot = &inp[k % NSLOT][0];
@@ -809,7 +810,7 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
           if (OUT_LAM) {
             double* lp = a.lam + (size_t)i * colB + bx;
 #pragma unroll
-            for (int q = 0; q < G; ++q) lp[(size_t)q * B] = c.lm[q];
+            for (int q = 0; q < G; ++q) __builtin_nontemporal_store(c.lm[q], &lp[(size_t)q * B]);
           }
           if (OUT_DJDU) {
             const double ev4 = LT ? c.e4 * lamcx : c.e4, ev3 = LT ? c.e3 * lamcx : c.e3, ev1 = LT ? c.e1 * lamcx : c.e1;
@@ -830,8 +831,8 @@ __global__ __launch_bounds__(256) void k_backward_pl(const BwdArgsPL a) {
             const double p1_s = (G == 1) ? pend : dpp_quad_pl<(G == 4) ? 0x90 : 0xA0>(p1);
             const double pabove = csub ? p1_s : pend;
             double* dp = a.dJdu + (size_t)(2 * i + 2) * B + bx;
-            *dp = pabove + p4;   // column 2i+2
-            *(dp - B) = p23;     // column 2i+1
+            __builtin_nontemporal_store(pabove + p4, dp);   // column 2i+2 (non-temporal: see ocs_scan_kernels.hip)
+            __builtin_nontemporal_store(p23, dp - B);       // column 2i+1
             pend = (G == 1) ? p1 : dpp_quad_pl<(G == 4) ? 0xFF : 0xF5>(p1);
             ucar = (G == 1) ? c.uA : dpp_quad_pl<(G == 4) ? 0xFF : 0xF5>(c.uA);
           }
@@ -1288,6 +1289,8 @@ int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const 
                       double* x, double* J, const int* frozen, double* dump, int ld, hipStream_t s,
                       bool no_cost_row, const int* gate) {
   if (!pipeline_shape_ok(p.nS, g.N, batch, false) || (frozen && !dump)) return -1;
+  static const bool v1 = getenv("OCS_FWD_V1") != nullptr;   // the previous kernel, for A/B timing
+  if (!v1) return launch_forward_p2(p, g, batch, x0, u, x, J, frozen, ld, s, no_cost_row, gate);
   FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump, ld, no_cost_row ? 1 : 0, gate};
 #ifdef OCS_PL_STAMPS
   static long long* dbg = nullptr;

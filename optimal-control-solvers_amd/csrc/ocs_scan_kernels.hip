@@ -92,10 +92,16 @@ struct Buf {
     return Buf{__builtin_amdgcn_make_buffer_rsrc(const_cast<double*>(p), 0, nrec, 0x00020000)};
   }
   __device__ inline double ld(unsigned voff, unsigned soff) const {
-    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, 0));
+#ifndef OCS_SCAN_LD_AUX
+#define OCS_SCAN_LD_AUX 0
+#endif
+    return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, OCS_SCAN_LD_AUX));
   }
   __device__ inline void st(double v, unsigned voff, unsigned soff) const {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_sc, v), r, voff, soff, 0);
+#ifndef OCS_SCAN_ST_AUX
+#define OCS_SCAN_ST_AUX 2   // nt: see the note on non-temporal stores at the top of the file
+#endif
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_sc, v), r, voff, soff, OCS_SCAN_ST_AUX);
   }
 };
 // 16-byte-per-lane LDS-DMA: lane l copies src_l[0..1] to lds_base[2l..2l+1]
@@ -184,7 +190,10 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
   auto load_part = [&](int sb, Ld& d, int slot, int q) OCS_INLINE {
     const int lo = chunk_lo(sb), lc = lo > 0 ? lo : 0;
     // the records first: older in the in-order queue than the loads the compiler waits for
-    if (q == 0) dma16_sc(a.RECS + (long long)(lo - 1) * kScanRec + 2 * lane, &rcs[slot][wave][0]);
+    // (a dead chunk -- below step 0, possibly far below in a superblock past the horizon -- takes zero records
+    //  from the front pad: identity maps)
+    const int lr = lo >= 0 ? lo - 1 : -kScanPadFront;
+    if (q == 0) dma16_sc(a.RECS + (long long)lr * kScanRec + 2 * lane, &rcs[slot][wave][0]);
     const Buf bx = Buf::make(a.xck + (size_t)lc * colB, ABL == 4 ? 0 : kNumRec), bu = Buf::make(a.u + (size_t)(2 * lc) * B, ABL == 4 ? 0 : kNumRec);
     d.x[q] = bx.ld(vx, (unsigned)q * col8);
     d.u[2 * q] = bu.ld(vu, (unsigned)(2 * q) * B8);
