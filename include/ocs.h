@@ -97,6 +97,21 @@ int ocs_problem_dFdx_times_vec(ocs_problem p, int k, const double *t, const doub
 int ocs_problem_dFdu_times_vec(ocs_problem p, int k, const double *t, const double *y, const double *u,
                                const double *v, double *out);
 
+/* [xStar, lamStar, uStar, resnorm, residual, exitflag] = compute_equilibrium(prob, xGuess, lamGuess, uGuess, lb, ub, r)
+ *                                                                   functions/compute_equilibrium.m:1-34
+ * Steady state of the optimality system, one instance per trajectory of the batch (per-trajectory parameters of `p`
+ * apply): y = [x; lam; u] with n = 2 nS + nC entries.  Device arrays, batch-minor: yGuess, y, residual [n][batch];
+ * lb, ub [n] (shared, as in the reference's call); resnorm [batch] (squared 2-norm of the residual, lsqnonlin's
+ * resnorm); exitflag [batch] (1 converged, 0 iteration limit).  residual may be NULL.  The host variant takes
+ * MATLAB-shaped arrays (n x batch, column-major) and batch = 1 reproduces the reference call.
+ * lsqnonlin is a MATLAB toolbox: the iteration here is a projected Levenberg-Marquardt with the reference's residual
+ * (:13-21); the root found from the same guess is the same.  Registry problems with nS <= 4 and user problems. */
+int ocs_compute_equilibrium_dev(ocs_problem p, int batch, double r, const double *yGuess, const double *lb,
+                                const double *ub, double *y, double *resnorm, double *residual, int *exitflag,
+                                void *stream);
+int ocs_compute_equilibrium(ocs_problem p, int batch, double r, const double *yGuess, const double *lb,
+                            const double *ub, double *y, double *resnorm, double *residual, int *exitflag);
+
 /* ---- Integrator (Integrator/Integrator.m:6-15) ---- */
 /* obj = RK4Integrator(tspan)                          Integrator/RK4Integrator.m:16-25 */
 int ocs_rk4_create(ocs_integrator *out, const double *tspan, int npts);

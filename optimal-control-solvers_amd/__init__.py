@@ -12,6 +12,6 @@ from .integrator import Integrator, RK4Integrator, RK4InfiniteIntegrator  # noqa
 from .control import Control, PWLinearControl, PWConstantControl, ChebyshevControl  # noqa: F401
 from .interp import vectorInterpolant, vectorInterpolant_dev, heval, linspace  # noqa: F401
 from .solvers import (nlp_objective, nlp_objective_dev, single_shooting, single_shooting_batch,  # noqa: F401
-                      compute_equilibrium)
+                      compute_equilibrium, compute_equilibrium_dev)
 from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, compute_x_lam, compute_x_lam_J  # noqa: F401
 from . import distributed  # noqa: F401

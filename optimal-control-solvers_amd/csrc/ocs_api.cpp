@@ -179,6 +179,65 @@ int ocs_problem_dFdu_times_vec(ocs_problem p, int k, const double* t, const doub
   return eval_common(p, 2, k, t, y, u, v, out);
 }
 
+// compute_equilibrium.m:1-34, batched (k_equilibrium)
+static int equilibrium_check(ocs_problem p, int batch) {
+  if (!p || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
+  if (p->functor == Functor::LQ) return fail(OCS_ERR_UNSUPPORTED, "compute_equilibrium: not instantiated for the LQ problem");
+  if (p->functor == Functor::User && 2 * p->nS + p->nC > 24)
+    return fail(OCS_ERR_UNSUPPORTED, "compute_equilibrium: at most 24 unknowns per instance");
+  if (p->pmask && p->pb_batch != batch)
+    return fail(OCS_ERR_SHAPE, "problem has per-trajectory parameters for batch %d, call has batch %d", p->pb_batch, batch);
+  return OCS_OK;
+}
+int ocs_compute_equilibrium_dev(ocs_problem p, int batch, double r, const double* yGuess, const double* lb,
+                                const double* ub, double* y, double* resnorm, double* residual, int* exitflag,
+                                void* stream) {
+  if (!yGuess || !lb || !ub || !y || !resnorm || !exitflag) return fail(OCS_ERR_INVALID, "null argument");
+  OCS_TRY(equilibrium_check(p, batch));
+  OCS_TRY(upload_problem(p));
+  // 4000 iterations is lsqnonlin's MaxIter in the reference (:24); the residual tolerance is round-off level
+  LAUNCH_TRY(launch_equilibrium(describe(p), batch, r, yGuess, lb, ub, y, resnorm, residual, exitflag, 4000, 1e-15,
+                                (hipStream_t)stream));
+  return OCS_OK;
+}
+int ocs_compute_equilibrium(ocs_problem p, int batch, double r, const double* yGuess, const double* lb,
+                            const double* ub, double* y, double* resnorm, double* residual, int* exitflag) {
+  if (!yGuess || !lb || !ub || !y || !resnorm || !exitflag) return fail(OCS_ERR_INVALID, "null argument");
+  OCS_TRY(equilibrium_check(p, batch));
+  const int n = 2 * p->nS + p->nC;
+  const size_t nb = (size_t)n * batch;
+  DevBuf dg, dl, du, dy, dr, dres, df, dst;
+  auto body = [&]() -> int {
+    OCS_TRY(dst.ensure(sizeof(double) * nb));
+    OCS_TRY(dg.ensure(sizeof(double) * nb));
+    OCS_TRY(dy.ensure(sizeof(double) * nb));
+    OCS_TRY(dres.ensure(sizeof(double) * nb));
+    OCS_TRY(dl.ensure(sizeof(double) * n));
+    OCS_TRY(du.ensure(sizeof(double) * n));
+    OCS_TRY(dr.ensure(sizeof(double) * batch));
+    OCS_TRY(df.ensure(sizeof(int) * batch));
+    HIP_TRY(hipMemcpy(dst.p, yGuess, sizeof(double) * nb, hipMemcpyHostToDevice));
+    LAUNCH_TRY(launch_to_batch_minor(dst.d(), dg.d(), n, batch, nullptr));
+    HIP_TRY(hipMemcpy(dl.p, lb, sizeof(double) * n, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(du.p, ub, sizeof(double) * n, hipMemcpyHostToDevice));
+    OCS_TRY(ocs_compute_equilibrium_dev(p, batch, r, dg.d(), dl.d(), du.d(), dy.d(), dr.d(), dres.d(), (int*)df.p,
+                                        nullptr));
+    LAUNCH_TRY(launch_to_traj_major(dy.d(), dst.d(), n, batch, nullptr));
+    HIP_TRY(hipMemcpy(y, dst.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    if (residual) {
+      LAUNCH_TRY(launch_to_traj_major(dres.d(), dst.d(), n, batch, nullptr));
+      HIP_TRY(hipMemcpy(residual, dst.p, sizeof(double) * nb, hipMemcpyDeviceToHost));
+    }
+    HIP_TRY(hipMemcpy(resnorm, dr.p, sizeof(double) * batch, hipMemcpyDeviceToHost));
+    HIP_TRY(hipMemcpy(exitflag, df.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
+    return OCS_OK;
+  };
+  const int rc = body();
+  DevBuf* all[] = {&dg, &dl, &du, &dy, &dr, &dres, &df, &dst};
+  for (DevBuf* q : all) q->release();
+  return rc;
+}
+
 // ------------------------------------------------------------------------------------
 // Integrator
 // ------------------------------------------------------------------------------------

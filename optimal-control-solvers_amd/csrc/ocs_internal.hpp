@@ -119,6 +119,10 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
 // which: 0 F, 1 dFdx_times_vec, 2 dFdu_times_vec; column-major device arrays with k columns.
 int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
                 const double* v, double* out, hipStream_t s);
+// batched compute_equilibrium (k_equilibrium, ocs_rk4_kernels.hpp): y0 / y / residual [2 nS + nC][B], lb / ub [2 nS + nC]
+int launch_equilibrium(const ProblemDesc& p, int batch, double r, const double* y0, const double* lb, const double* ub,
+                       double* y, double* resnorm, double* residual, int* exitflag, int max_iter, double tol,
+                       hipStream_t s);
 // layout helpers; per = doubles per trajectory
 int launch_to_batch_minor(const double* src, double* dst, int per, int batch, hipStream_t s);
 int launch_to_traj_major(const double* src, double* dst, int per, int batch, hipStream_t s);

@@ -79,6 +79,7 @@ static std::vector<std::string> kernel_names(int nS) {
   n[UK_CONTROL_GRID] = "ocs::k_control_grid<ocs::UserP>";
   n[UK_CONTROL_PTS] = "ocs::k_control_pts<ocs::UserP>";
   n[UK_TU_AT] = "ocs::k_tu_at<ocs::UserP>";
+  n[UK_EQUILIBRIUM] = "ocs::k_equilibrium<ocs::UserP>";
   return n;
 }
 

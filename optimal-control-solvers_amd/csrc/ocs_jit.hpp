@@ -9,7 +9,7 @@ namespace ocs {
 
 enum UserKernel : int {
   UK_TCOEF = 0, UK_BUILD_REC, UK_FWD_X, UK_FWD_J, UK_FWD_UCONST, UK_BWD_LAM_DJDU, UK_BWD_LAM, UK_BWD_DJDU,
-  UK_BWD_UCONST, UK_EVAL, UK_COSTATE, UK_CONTROL_GRID, UK_CONTROL_PTS, UK_TU_AT, UK_COUNT
+  UK_BWD_UCONST, UK_EVAL, UK_COSTATE, UK_CONTROL_GRID, UK_CONTROL_PTS, UK_TU_AT, UK_EQUILIBRIUM, UK_COUNT
 };
 
 struct UserModule {

@@ -316,6 +316,23 @@ int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const d
   return hip_rc(hipGetLastError());
 }
 
+template <class P>
+static void run_equilibrium(const EqArgs& a, hipStream_t s) {
+  k_equilibrium<P><<<dim3((a.batch + 63) / 64), dim3(64), 0, s>>>(a);
+}
+int launch_equilibrium(const ProblemDesc& p, int batch, double r, const double* y0, const double* lb, const double* ub,
+                       double* y, double* resnorm, double* residual, int* exitflag, int max_iter, double tol,
+                       hipStream_t s) {
+  const EqArgs a{batch, r, p.ps, p.pb, p.pmask, y0, lb, ub, y, resnorm, residual, exitflag, max_iter, tol};
+  if (p.functor == Functor::User) {
+    void* args[] = {(void*)&a};
+    return jit_launch(p.user, UK_EQUILIBRIUM, dim3((batch + 63) / 64), dim3(64), args, s);
+  }
+  if (p.functor != Functor::Logistic) return -1;
+  OCS_DISPATCH_LOGISTIC(p.nS, run_equilibrium<P>(a, s));
+  return hip_rc(hipGetLastError());
+}
+
 // traj-major [batch][per]  ->  batch-minor [per][batch]
 int launch_to_batch_minor(const double* src, double* dst, int per, int batch, hipStream_t s) {
   hipLaunchKernelGGL(k_transpose, dim3((per + 63) / 64, (batch + 63) / 64), dim3(256), 0, s, src, dst, batch,

@@ -508,4 +508,165 @@ __global__ void k_eval(int which, int kcols, const double* __restrict__ t, const
 }
 
 
+// ---------------------------------------------------------------------------------------
+// compute_equilibrium (functions/compute_equilibrium.m:10-27), batched: one thread per instance solves the
+// (2 nS + nC)-dimensional steady-state system of the optimality conditions
+//     F(0, x, u)(1:nS) = 0,   r lam - dFdx_times_vec(0, x, u, [lam; 1])(1:nS) = 0,   dFdu_times_vec(0, x, u, [lam; 1]) = 0
+// inside the box lb <= y <= ub, y = [x; lam; u], with a projected Levenberg-Marquardt iteration.  The reference
+// hands the same residual to lsqnonlin (a MATLAB toolbox; trust-region-reflective with a finite-difference
+// Jacobian); here the Jacobian is a central difference of the plugin methods as well, so any OCProblem works
+// unchanged, and since the residual itself is exact the iteration still converges to round-off.
+// ---------------------------------------------------------------------------------------
+struct EqArgs {
+  int batch;
+  double r;
+  const double* ps;
+  const double* pb;
+  unsigned pmask;
+  const double* y0;      // [n][B] initial guesses (clamped to the bounds, compute_equilibrium.m:26-27 via lsqnonlin)
+  const double* lb;      // [n]
+  const double* ub;      // [n]
+  double* y;             // [n][B]
+  double* resnorm;       // [B] squared 2-norm of the residual
+  double* residual;      // [n][B] or nullptr
+  int* exitflag;         // [B]: 1 converged (residual at round-off or no further decrease possible), 0 iteration limit
+  int max_iter;
+  double tol;            // stop when the max-norm of the residual is below tol (relative to max(1, |terms|))
+};
+
+template <class P>
+__global__ __launch_bounds__(64) void k_equilibrium(const EqArgs a) {
+  constexpr int NS = P::NS, NC = P::NC, NAUG = P::NAUG, NV = 2 * NS + NC;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= a.batch) return;
+  const size_t B = (size_t)a.batch;
+  const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
+  double tc[P::NTC], tu[P::NTU];
+  P::tcoef(0.0, a.ps, tc, tu);
+  auto residual = [&](const double* yv, double* R) {
+    double xx[NS], uu[NC], vv[NAUG], f[NAUG], g[NS], gu[NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      xx[k] = yv[k];
+      vv[k] = yv[NS + k];
+    }
+    vv[NS] = 1.0;
+#pragma unroll
+    for (int k = 0; k < NC; ++k) uu[k] = yv[2 * NS + k];
+    P::F(tc, xx, uu, p, f);                      // :16-17
+    P::dFdxT(tc, xx, uu, p, vv, g);              // :19-20
+    P::dFduT(tc, xx, uu, p, vv, gu);             // :22
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      R[k] = f[k];
+      R[NS + k] = a.r * vv[k] - g[k];
+    }
+#pragma unroll
+    for (int k = 0; k < NC; ++k) R[2 * NS + k] = gu[k];
+  };
+  double y[NV], lo[NV], hi[NV], R[NV];
+  for (int k = 0; k < NV; ++k) {
+    lo[k] = a.lb[k];
+    hi[k] = a.ub[k];
+    y[k] = fmin(hi[k], fmax(lo[k], a.y0[(size_t)k * B + b]));
+  }
+  residual(y, R);
+  double cost = 0.0;
+  for (int k = 0; k < NV; ++k) cost += R[k] * R[k];
+  double mu = 1e-3;
+  int flag = 0;
+  for (int it = 0; it < a.max_iter; ++it) {
+    double rmax = 0.0;
+    for (int k = 0; k < NV; ++k) rmax = fmax(rmax, fabs(R[k]));
+    if (rmax <= a.tol) {
+      flag = 1;
+      break;
+    }
+    // Jacobian by central differences, one column at a time (kept inside the box: one-sided at an active bound)
+    double Jm[NV][NV];
+    for (int j = 0; j < NV; ++j) {
+      const double hstep = 6.0554544523933395e-06 * fmax(1.0, fabs(y[j]));   // eps^(1/3)
+      double yp[NV], ym[NV], Rp[NV], Rm[NV];
+      for (int k = 0; k < NV; ++k) yp[k] = ym[k] = y[k];
+      yp[j] = fmin(hi[j], y[j] + hstep);
+      ym[j] = fmax(lo[j], y[j] - hstep);
+      residual(yp, Rp);
+      residual(ym, Rm);
+      const double inv = 1.0 / (yp[j] - ym[j]);
+      for (int k = 0; k < NV; ++k) Jm[k][j] = (Rp[k] - Rm[k]) * inv;
+    }
+    // normal equations (J'J + mu diag(J'J)) d = -J'R, solved by Gaussian elimination with partial pivoting;
+    // variables sitting on a bound with the step pointing outward are frozen (projected step)
+    double Am[NV][NV], gv[NV];
+    for (int i = 0; i < NV; ++i) {
+      double s = 0.0;
+      for (int k = 0; k < NV; ++k) s += Jm[k][i] * R[k];
+      gv[i] = s;
+      for (int j = 0; j < NV; ++j) {
+        double t = 0.0;
+        for (int k = 0; k < NV; ++k) t += Jm[k][i] * Jm[k][j];
+        Am[i][j] = t;
+      }
+    }
+    bool improved = false;
+    for (int tries = 0; tries < 12 && !improved; ++tries) {
+      double M[NV][NV + 1];
+      for (int i = 0; i < NV; ++i) {
+        const bool frozen = (y[i] <= lo[i] && gv[i] > 0.0) || (y[i] >= hi[i] && gv[i] < 0.0);
+        for (int j = 0; j < NV; ++j) M[i][j] = frozen ? (i == j ? 1.0 : 0.0) : Am[i][j];
+        if (!frozen) M[i][i] += mu * fmax(Am[i][i], 1e-300);
+        M[i][NV] = frozen ? 0.0 : -gv[i];
+      }
+      for (int c = 0; c < NV; ++c) {
+        int piv = c;
+        for (int i = c + 1; i < NV; ++i)
+          if (fabs(M[i][c]) > fabs(M[piv][c])) piv = i;
+        for (int j = 0; j <= NV; ++j) {
+          const double t = M[c][j];
+          M[c][j] = M[piv][j];
+          M[piv][j] = t;
+        }
+        const double d = M[c][c];
+        const double inv = d != 0.0 ? 1.0 / d : 0.0;
+        for (int i = c + 1; i < NV; ++i) {
+          const double fct = M[i][c] * inv;
+          for (int j = c; j <= NV; ++j) M[i][j] -= fct * M[c][j];
+        }
+      }
+      double dlt[NV];
+      for (int i = NV - 1; i >= 0; --i) {
+        double s = M[i][NV];
+        for (int j = i + 1; j < NV; ++j) s -= M[i][j] * dlt[j];
+        dlt[i] = M[i][i] != 0.0 ? s / M[i][i] : 0.0;
+      }
+      double yn[NV], Rn[NV], cn = 0.0;
+      for (int k = 0; k < NV; ++k) yn[k] = fmin(hi[k], fmax(lo[k], y[k] + dlt[k]));
+      residual(yn, Rn);
+      for (int k = 0; k < NV; ++k) cn += Rn[k] * Rn[k];
+      if (cn < cost) {
+        for (int k = 0; k < NV; ++k) {
+          y[k] = yn[k];
+          R[k] = Rn[k];
+        }
+        cost = cn;
+        mu = fmax(mu * (1.0 / 3.0), 1e-15);
+        improved = true;
+      } else {
+        mu *= 4.0;
+      }
+    }
+    if (!improved) {   // no decrease at any damping: at round-off level of the residual, or at a constrained minimum
+      flag = 1;
+      break;
+    }
+  }
+  for (int k = 0; k < NV; ++k) {
+    a.y[(size_t)k * B + b] = y[k];
+    if (a.residual) a.residual[(size_t)k * B + b] = R[k];
+  }
+  a.resnorm[b] = cost;
+  a.exitflag[b] = flag;
+}
+
+
 }  // namespace ocs

@@ -123,32 +123,42 @@ def compute_equilibrium(prob, xGuess, lamGuess, uGuess, lb, ub, r):
     """[xStar, lamStar, uStar, resnorm, residual, exitflag] = compute_equilibrium(prob, xGuess, lamGuess,
     uGuess, lb, ub, r)   functions/compute_equilibrium.m:1-34.
     Steady state of the optimality system: F(0,x,u)(1:nS) = 0, r*lam - dFdx_times_vec(0,x,u,[lam;1])(1:nS) = 0,
-    dFdu_times_vec(0,x,u,[lam;1]) = 0 (:10-21).  The plugin methods are evaluated by the device functor; the
-    bounded nonlinear least-squares driver is scipy's trust-region-reflective `least_squares`, the algorithm
-    family of MATLAB's lsqnonlin (a toolbox that does not exist here), with the reference's TolFun 1e-10."""
-    from scipy.optimize import least_squares
-    xGuess, lamGuess, uGuess = (np.atleast_1d(np.asarray(a, dtype=np.float64)) for a in (xGuess, lamGuess, uGuess))
-    nS, nC = xGuess.size, uGuess.size
-    xi, li, ui = slice(0, nS), slice(nS, 2 * nS), slice(2 * nS, 2 * nS + nC)
+    dFdu_times_vec(0,x,u,[lam;1]) = 0 (:10-21), inside lb <= [x; lam; u] <= ub.  Solved on the device
+    (ocs_compute_equilibrium: one thread per instance, projected Levenberg-Marquardt on the reference's residual;
+    lsqnonlin is a MATLAB toolbox).  Guesses may carry a trailing batch dimension (nS x B, nS x B, nC x B): every
+    column is one instance (with the per-trajectory parameters of `prob`), and the outputs gain that dimension."""
+    xG, lG, uG = (np.asarray(a, dtype=np.float64) for a in (xGuess, lamGuess, uGuess))
+    batched = xG.ndim == 2
+    nS, nC = prob.nS, prob.ControlBounds.shape[0]
+    B = xG.shape[1] if batched else 1
+    yG = np.asfortranarray(np.vstack([xG.reshape(nS, B), lG.reshape(nS, B), uG.reshape(nC, B)]))
+    n = 2 * nS + nC
+    lb = np.ascontiguousarray(np.asarray(lb, dtype=np.float64).ravel())
+    ub = np.ascontiguousarray(np.asarray(ub, dtype=np.float64).ravel())
+    if lb.size != n or ub.size != n:
+        raise ValueError(f"lb, ub need {n} entries ([x; lam; u])")
+    y = np.empty((n, B), order="F")
+    res = np.empty((n, B), order="F")
+    resnorm = np.empty(B)
+    flag = np.empty(B, dtype=np.int32)
+    check(lib.ocs_compute_equilibrium(prob._h, B, float(r), _p(yG), _p(lb), _p(ub), _p(y), _p(resnorm), _p(res),
+                                      flag.ctypes.data_as(C.POINTER(C.c_int))))
+    if batched:
+        return y[:nS], y[nS:2 * nS], y[2 * nS:], resnorm, res, flag
+    return y[:nS, 0], y[nS:2 * nS, 0], y[2 * nS:, 0], float(resnorm[0]), res[:, 0], int(flag[0])
 
-    def equilibrium_system(y):                                            # :13-21
-        x, lam, u = y[xi], y[li], y[ui]
-        ya = np.concatenate([x, [0.0]])
-        va = np.concatenate([lam, [1.0]])
-        value = np.zeros_like(y)
-        value[xi] = prob.F(0.0, ya, u)[:nS, 0]
-        value[li] = r * lam - prob.dFdx_times_vec(0.0, ya, u, va)[:nS, 0]
-        value[ui] = prob.dFdu_times_vec(0.0, ya, u, va)[:, 0]
-        return value
 
-    y0 = np.concatenate([xGuess, lamGuess, uGuess])
-    lb = np.asarray(lb, dtype=np.float64).ravel()
-    ub = np.asarray(ub, dtype=np.float64).ravel()
-    y0 = np.minimum(np.maximum(y0, lb), ub)
-    res = least_squares(equilibrium_system, y0, bounds=(lb, ub), method="trf", ftol=1e-10, xtol=1e-14, gtol=1e-14,
-                        max_nfev=1000 * (2 * nS + nC))                    # :23-27
-    y = res.x
-    return y[xi], y[li], y[ui], float(2 * res.cost), res.fun, int(res.status)
+def compute_equilibrium_dev(prob, yGuess, lb, ub, r):
+    """device, batch-minor: yGuess [2 nS + nC][B] -> (y [n][B], resnorm [B], residual [n][B], exitflag [B] int32);
+    lb, ub: device [n].  Asynchronous on the current stream."""
+    n, B = yGuess.shape
+    y, res = torch.empty_like(yGuess), torch.empty_like(yGuess)
+    resnorm = torch.empty(B, dtype=torch.float64, device=yGuess.device)
+    flag = torch.empty(B, dtype=torch.int32, device=yGuess.device)
+    assert lb.numel() == n and ub.numel() == n and yGuess.is_contiguous() and yGuess.dtype == torch.float64
+    check(lib.ocs_compute_equilibrium_dev(prob._h, B, float(r), _dptr(yGuess), _dptr(lb), _dptr(ub), _dptr(y),
+                                          _dptr(resnorm), _dptr(res), C.c_void_p(flag.data_ptr()), _stream()))
+    return y, resnorm, res, flag
 
 
 def single_shooting_batch(prob, x0, tspan, nCONTROL_PTS, Control=None, Integrator=None, u0=0.0, TolX=1e-5,

@@ -187,6 +187,82 @@ def test_compute_equilibrium_and_solve_test_problem_script(ocs, oracle):
     assert plain["u"](np.array([10.0]))[0, 0] < 0.2  # finite horizon: harvest drops at the end (lam(T) = 0)
 
 
+def _testoc_equilibrium(c, m, r):
+    """interior root of the optimality system of TestOCProblem (analytic): with lam = 2 c u (dFdu' [lam;1] = 0 at
+    t = 0), x' = 0: u = x (m - x), costate: (r - m + 2 x) lam = 2 x  ->  one equation in x, solved by bisection on the
+    branch x in (m/2, m) (the root compute_equilibrium converges to from the reference's guess)."""
+    # x != 0: (r - m + 2 x) c (m - x) = 1, a downward parabola minus 1; the feasible root (u <= 1) is the upper one,
+    # between the vertex and m
+    f = lambda x: (r - m + 2 * x) * c * (m - x) - 1.0
+    lo, hi = (3 * m - r) / 4, m
+    for _ in range(200):
+        mid = 0.5 * (lo + hi)
+        lo, hi = (mid, hi) if f(mid) > 0 else (lo, mid)
+    x = 0.5 * (lo + hi)
+    u = x * (m - x)
+    return x, 2 * c * u, u
+
+
+def test_compute_equilibrium_batched_on_device(ocs, oracle):
+    """compute_equilibrium.m:10-27 as a batch: 4096 instances with per-instance c, every one against the analytic root
+    and against the oracle-side residual; the device entry point; the reference's known answer from its guess."""
+    import torch
+    B = 4096
+    rng = np.random.default_rng(21)
+    cs = rng.uniform(1.2, 2.0, B)
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    lb, ub = [0.0, -np.inf, 0.0], [np.inf, np.inf, 1.0]                          # solve_test_problem.m:25-26
+    xG, lG, uG = np.full((1, B), 2.7), np.full((1, B), 2.2), np.full((1, B), 0.7)
+    xs, ls, us, resnorm, res, flag = ocs.compute_equilibrium(prob, xG, lG, uG, lb, ub, P["r"])
+    assert np.all(flag == 1) and np.max(resnorm) < 1e-24
+    ref = np.array([_testoc_equilibrium(c, P["m"], P["r"]) for c in cs]).T
+    assert np.max(np.abs(xs[0] - ref[0])) < 1e-11 and np.max(np.abs(ls[0] - ref[1])) < 1e-11
+    assert np.max(np.abs(us[0] - ref[2])) < 1e-11
+    # oracle-side residual of the reference's system (compute_equilibrium.m:13-21) at the device's answer
+    for b in (0, 1, 777, B - 1):
+        po = oracle.TestOCProblem({"c": cs[b], "m": P["m"], "r": P["r"]}, BOUNDS)
+        y = np.array([xs[0, b], 0.0])
+        F = po.F([0.0], y, [us[0, b]]).ravel()
+        g = po.dFdx_times_vec([0.0], y, [us[0, b]], np.array([ls[0, b], 1.0])).ravel()
+        gu = po.dFdu_times_vec([0.0], y, [us[0, b]], np.array([ls[0, b], 1.0])).ravel()
+        assert abs(F[0]) < 1e-12 and abs(P["r"] * ls[0, b] - g[0]) < 1e-12 and abs(gu[0]) < 1e-12
+    # SURVEY KAT 1 (c = 1.5) through the single-instance call of the reference's signature
+    p1 = ocs.TestOCProblem(P, BOUNDS)
+    x1, l1, u1, rn, _, fl = ocs.compute_equilibrium(p1, 2.7, 2.2, 0.7, lb, ub, P["r"])
+    assert fl == 1 and rn < 1e-24
+    assert abs(x1[0] - 2.7355691886341361) < 1e-12 and abs(l1[0] - 2.1701063402939477) < 1e-12
+    assert abs(u1[0] - 0.72336878009798256) < 1e-12
+    # device entry point, asynchronous, same answers
+    dev = torch.device("cuda:0")
+    yG = torch.tensor(np.vstack([xG, lG, uG]), device=dev)
+    lbd = torch.tensor([0.0, -1e300, 0.0], dtype=torch.float64, device=dev)
+    ubd = torch.tensor([1e300, 1e300, 1.0], dtype=torch.float64, device=dev)
+    yd, rnd, resd, fld = ocs.compute_equilibrium_dev(prob, yG, lbd, ubd, P["r"])
+    torch.cuda.synchronize()
+    assert np.max(np.abs(yd.cpu().numpy() - np.vstack([xs, ls, us]))) < 1e-13 and bool((fld == 1).all())
+    # an active bound: u <= 0.5 -> the constrained least-squares point sits on the bound, exitflag still 1
+    xb, lbm, ub_, rnb, _, flb = ocs.compute_equilibrium(p1, 2.7, 2.2, 0.4, lb, [np.inf, np.inf, 0.5], P["r"])
+    assert flb == 1 and abs(ub_[0] - 0.5) < 1e-15 and rnb > 1e-6
+    # a two-state registry problem (five unknowns): its optimality system has NO steady state (the two logistic rows
+    # cannot both balance one harvest rate with positive costates); lsqnonlin then returns the least-squares point, and
+    # so must this: compare with scipy's trust-region-reflective solver on the oracle's plugin methods
+    from scipy.optimize import least_squares
+    m2 = [3.0, 2.5]
+    p2, po2 = ocs.LogisticProblem(m2, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m2, P["c"], P["r"], BOUNDS)
+    lb2, ub2 = [0, 0, -np.inf, -np.inf, 0], [np.inf] * 5
+
+    def system(y):                                                         # compute_equilibrium.m:13-21
+        ya, va = np.array([y[0], y[1], 0.0]), np.array([y[2], y[3], 1.0])
+        return np.concatenate([po2.F([0.0], ya, y[4:]).ravel()[:2],
+                               P["r"] * y[2:4] - po2.dFdx_times_vec([0.0], ya, y[4:], va).ravel()[:2],
+                               po2.dFdu_times_vec([0.0], ya, y[4:], va).ravel()])
+    ref2 = least_squares(system, [2.6, 2.1, 1.2, 1.2, 0.6], bounds=(lb2, ub2), xtol=1e-15, ftol=1e-15, gtol=1e-15)
+    x2, l2, u2, rn2, res2, fl2 = ocs.compute_equilibrium(p2, [2.6, 2.1], [1.2, 1.2], [0.6], lb2, ub2, P["r"])
+    assert fl2 == 1 and abs(rn2 - 2 * ref2.cost) < 1e-10 and rn2 > 0.1
+    assert np.max(np.abs(np.concatenate([x2, l2, u2]) - ref2.x)) < 1e-6
+
+
 def test_single_shooting_batch_on_device(ocs, oracle):
     """a batch of independent shooting NLPs (different x0 and c) solved together by the
     batched projected-gradient driver; every instance must reach the optimum the oracle-driven SLSQP finds."""

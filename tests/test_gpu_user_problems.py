@@ -55,6 +55,13 @@ def test_hand_written_logistic2_equals_builtin_and_oracle(ocs, oracle):
     _, Jo = go.compute_states(oracle.LogisticProblem(m, cs[5], r, BOUNDS), x0[:, 5], uu[:, :, 5])
     assert abs(Jc[5] - Jo) < RTOL * abs(Jo)
     pu.set_batch_params([], None)
+    # compute_equilibrium on the user's plugin methods (hipRTC instance of k_equilibrium) == the registry problem's
+    big = [np.inf] * 2
+    lb, ub = [0, 0, -np.inf, -np.inf, 0], big + big + [np.inf]
+    eu = ocs.compute_equilibrium(pu, [2.6, 2.1], [1.2, 1.2], [0.6], lb, ub, r)
+    eb = ocs.compute_equilibrium(pb, [2.6, 2.1], [1.2, 1.2], [0.6], lb, ub, r)
+    # (this system has no root: both return the same least-squares point, see test_compute_equilibrium_batched_on_device)
+    assert eu[5] == 1 and abs(eu[3] - eb[3]) < 1e-12 and relerr(np.concatenate(eu[:3]), np.concatenate(eb[:3])) < 1e-9
     # fb_sweep through the user's ocs_ControlChar
     s1 = ocs.fb_sweep_batch(pu, np.array([[1.0], [1.5]]), oracle.linspace(0, 8, 161), {"nERROR_PTS": 161, "nINTERP_PTS": 81})
     s2 = oracle.fb_sweep(po, [1.0, 1.5], oracle.linspace(0, 8, 161), {"nERROR_PTS": 161, "nINTERP_PTS": 81})
