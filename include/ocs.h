@@ -136,6 +136,15 @@ int ocs_integrator_h(ocs_integrator g, double *h);        /* obj.h, N values    
  * Returns OCS_NUM_NONFINITE if any J is not finite (results are still written). */
 int ocs_compute_states(ocs_integrator g, ocs_problem p, int batch, const double *x0, const double *u,
                        double *x, double *J);
+/* Per-trajectory status (the reference has no counterpart: it integrates one trajectory per call and never checks
+ * for NaN/Inf): status[b] = OCS_NUM_NONFINITE if the objective of trajectory b is NaN/Inf -- any non-finite stage
+ * state makes it so -- else 0.  Device variant: from a device array J [batch], asynchronous on `stream`; host variant:
+ * the flags of the handle's last ocs_compute_states / ocs_nlp_objective call. */
+int ocs_trajectory_status_dev(int batch, const double *J, int *status, void *stream);
+int ocs_integrator_trajectory_status(ocs_integrator g, int batch, int *status);
+/* 1 if a roctx marker library was found at run time (every compute entry point then opens a named range) */
+int ocs_tracing_enabled(void);
+
 /* [lam, dJdu] = compute_adjoints(obj, prob, u, lamT)  RK4Integrator.m:59-121
  * lamT nAug x batch or NULL (default e_last, :63-66); dJdu may be NULL (nargout == 1). */
 int ocs_compute_adjoints(ocs_integrator g, ocs_problem p, int batch, const double *u, const double *lamT,
@@ -144,7 +153,11 @@ int ocs_compute_adjoints(ocs_integrator g, ocs_problem p, int batch, const doubl
  * lamT [nAug][batch], lam [N+1][nAug][batch], dJdu [2N+1][nC][batch].
  * If x is non-NULL it doubles as the checkpoint store the adjoint pass re-reads: keep it
  * alive and unmodified until compute_adjoints_dev has run (the xK contract of the reference).
- * lam may be NULL when only dJdu is wanted. */
+ * lam may be NULL when only dJdu is wanted.
+ * Streams: a handle (integrator, control, problem) owns scratch buffers and cached tables; use it from ONE stream at
+ * a time.  Switching to another stream between calls is safe: the tables built on the earlier stream are ordered in
+ * front of the new stream's kernels by an event; work still in flight on the earlier stream that uses the handle's
+ * scratch is not -- synchronise it first. */
 int ocs_compute_states_dev(ocs_integrator g, ocs_problem p, int batch, const double *x0, const double *u,
                            double *x, double *J, void *stream);
 int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const double *u,

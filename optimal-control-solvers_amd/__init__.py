@@ -7,8 +7,14 @@ The directory name is not a Python identifier; load it with
 """
 from . import _lib  # noqa: F401  fails loudly when libocs.so is missing
 from ._lib import OcsError  # noqa: F401
+
+
+def tracing_enabled():
+    """True if a roctx marker library was found: every compute entry point then opens a named range"""
+    return bool(_lib.lib.ocs_tracing_enabled())
+
 from .problem import OCProblem, TestOCProblem, LogisticProblem, LQProblem, UserProblem  # noqa: F401
-from .integrator import Integrator, RK4Integrator, RK4InfiniteIntegrator  # noqa: F401
+from .integrator import Integrator, RK4Integrator, RK4InfiniteIntegrator, trajectory_status_dev  # noqa: F401
 from .control import Control, PWLinearControl, PWConstantControl, ChebyshevControl  # noqa: F401
 from .interp import vectorInterpolant, vectorInterpolant_dev, heval, linspace  # noqa: F401
 from .solvers import (nlp_objective, nlp_objective_dev, single_shooting, single_shooting_batch,  # noqa: F401

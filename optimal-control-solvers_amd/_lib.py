@@ -54,6 +54,9 @@ _SIG = {
     "ocs_problem_dFdu_times_vec": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp]),
     "ocs_compute_equilibrium": (C.c_int, [vp, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, ip]),
     "ocs_compute_equilibrium_dev": (C.c_int, [vp, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ocs_trajectory_status_dev": (C.c_int, [C.c_int, vp, vp, vp]),
+    "ocs_integrator_trajectory_status": (C.c_int, [vp, C.c_int, ip]),
+    "ocs_tracing_enabled": (C.c_int, []),
     "ocs_rk4_create": (C.c_int, [C.POINTER(vp), dp, C.c_int]),
     "ocs_integrator_destroy": (C.c_int, [vp]),
     "ocs_integrator_set_mapping": (C.c_int, [vp, C.c_int]),

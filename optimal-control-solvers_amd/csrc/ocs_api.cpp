@@ -2,6 +2,7 @@
 // validation, host<->device staging and layout conversion around the gfx950 kernels.
 // No compute happens on the host here; if no MI355X is usable every compute entry point
 // fails with OCS_ERR_NO_DEVICE.
+#include "ocs_trace.hpp"
 #include "ocs_handles.hpp"
 
 using namespace ocs;
@@ -87,6 +88,7 @@ int ocs_problem_create(ocs_problem* out, int problem_id, int nS, int nC, const d
 
 int ocs_problem_destroy(ocs_problem p) {
   if (!p) return OCS_OK;
+  if (p->shadow) ocs_problem_destroy(p->shadow);
   if (p->user) jit_free(p->user);
   p->d_ps.release();
   p->d_pb.release();
@@ -192,6 +194,7 @@ static int equilibrium_check(ocs_problem p, int batch) {
 int ocs_compute_equilibrium_dev(ocs_problem p, int batch, double r, const double* yGuess, const double* lb,
                                 const double* ub, double* y, double* resnorm, double* residual, int* exitflag,
                                 void* stream) {
+  OCS_TRACE("ocs_compute_equilibrium_dev");
   if (!yGuess || !lb || !ub || !y || !resnorm || !exitflag) return fail(OCS_ERR_INVALID, "null argument");
   OCS_TRY(equilibrium_check(p, batch));
   OCS_TRY(upload_problem(p));
@@ -202,6 +205,7 @@ int ocs_compute_equilibrium_dev(ocs_problem p, int batch, double r, const double
 }
 int ocs_compute_equilibrium(ocs_problem p, int batch, double r, const double* yGuess, const double* lb,
                             const double* ub, double* y, double* resnorm, double* residual, int* exitflag) {
+  OCS_TRACE("ocs_compute_equilibrium");
   if (!yGuess || !lb || !ub || !y || !resnorm || !exitflag) return fail(OCS_ERR_INVALID, "null argument");
   OCS_TRY(equilibrium_check(p, batch));
   const int n = 2 * p->nS + p->nC;
@@ -284,6 +288,7 @@ int ocs_rk4inf_create(ocs_integrator* out, const double* tspan, int npts, const 
 }
 
 int ocs_integrator_destroy(ocs_integrator g) {
+  if (g && g->tc_event) (void)hipEventDestroy(g->tc_event);
   if (!g) return OCS_OK;
   if (g->leg2) ocs_integrator_destroy(g->leg2);
   if (g->fbs) ocs_fbs_state_free(g->fbs);
@@ -341,6 +346,7 @@ static int leg_forward(ocs_integrator_s* g, ocs_problem_s* p, int batch, const d
 
 int ocs_compute_states_dev(ocs_integrator g, ocs_problem p, int batch, const double* x0, const double* u,
                            double* x, double* J, void* stream) {
+  OCS_TRACE("ocs_compute_states_dev");
   if (!g || !p || !x0 || !u || !J) return fail(OCS_ERR_INVALID, "null argument");
   if (batch < 1) return fail(OCS_ERR_SHAPE, "batch must be >= 1");
   hipStream_t s = (hipStream_t)stream;
@@ -362,6 +368,7 @@ int ocs_compute_states_dev(ocs_integrator g, ocs_problem p, int batch, const dou
 
 int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const double* u, const double* lamT,
                              double* lam, double* dJdu, void* stream) {
+  OCS_TRACE("ocs_compute_adjoints_dev");
   if (!g || !p || !u) return fail(OCS_ERR_INVALID, "null argument");
   if (!lam && !dJdu) return fail(OCS_ERR_INVALID, "at least one of lam, dJdu must be requested");
   if (!g->ck || g->ck_prob != p || g->ck_batch != batch)
@@ -414,6 +421,7 @@ static int stage_out(ocs_integrator_s* g, const DevBuf& src, double* host, int p
 
 int ocs_compute_states(ocs_integrator g, ocs_problem p, int batch, const double* x0, const double* u,
                        double* x, double* J) {
+  OCS_TRACE("ocs_compute_states");
   if (!g || !p || !x0 || !u || !J) return fail(OCS_ERR_INVALID, "null argument");
   if (batch < 1) return fail(OCS_ERR_SHAPE, "batch must be >= 1");
   OCS_TRY(upload_grid(g));
@@ -431,13 +439,34 @@ int ocs_compute_states(ocs_integrator g, ocs_problem p, int batch, const double*
   } else {
     HIP_TRY(hipStreamSynchronize(g->stream));
   }
+  g->traj_status.assign(batch, 0);
+  int rc = OCS_OK;
   for (int b = 0; b < batch; ++b)
-    if (!std::isfinite(J[b])) return OCS_NUM_NONFINITE;
+    if (!std::isfinite(J[b])) {
+      g->traj_status[b] = OCS_NUM_NONFINITE;
+      rc = OCS_NUM_NONFINITE;
+    }
+  return rc;
+}
+
+int ocs_integrator_trajectory_status(ocs_integrator g, int batch, int* status) {
+  if (!g || !status) return fail(OCS_ERR_INVALID, "null argument");
+  if ((int)g->traj_status.size() != batch)
+    return fail(OCS_ERR_ORDER, "no host compute call with batch %d has run on this handle", batch);
+  for (int b = 0; b < batch; ++b) status[b] = g->traj_status[b];
   return OCS_OK;
 }
+int ocs_trajectory_status_dev(int batch, const double* J, int* status, void* stream) {
+  if (!J || !status || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(require_device());
+  LAUNCH_TRY(launch_traj_status(J, batch, status, (hipStream_t)stream));
+  return OCS_OK;
+}
+int ocs_tracing_enabled(void) { return roctx_available() ? 1 : 0; }
 
 int ocs_compute_adjoints(ocs_integrator g, ocs_problem p, int batch, const double* u, const double* lamT,
                          double* lam, double* dJdu) {
+  OCS_TRACE("ocs_compute_adjoints");
   if (!g || !p || !u || !lam) return fail(OCS_ERR_INVALID, "null argument");
   if (!g->ck || g->ck != g->d_x.d() || g->ck_prob != p || g->ck_batch != batch)
     return fail(OCS_ERR_ORDER, "compute_adjoints needs compute_states first on the same handle/problem/batch");

@@ -2,6 +2,7 @@
 // vectorInterpolant sampling, and the single_shooting objective (single_shooting.m:137-150).
 // The basis matrix is built on the host exactly once per handle, like the reference's
 // constructors do; all per-trajectory arithmetic runs in the kernels.
+#include "ocs_trace.hpp"
 #include "ocs_handles.hpp"
 
 #include <algorithm>
@@ -304,6 +305,7 @@ int ocs_control_points(ocs_control c, double* pts) {
 
 // u = compute_u(obj, v)          PWLinearControl.m:59-62 (and twins)
 int ocs_control_compute_u_dev(ocs_control c, int batch, const double* v, double* u, void* stream) {
+  OCS_TRACE("ocs_control_compute_u_dev");
   if (!c || !v || !u || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_control(c));
   if (c->dense && batch >= 16384) {  // below that the time-parallel sparse kernel fills the chip better
@@ -455,6 +457,7 @@ int ocs_control_eval_uFunc(ocs_control c, const double* v, int nq, const double*
 // FreeInitStates is a host array of 1-based state indices like MATLAB's.
 int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int batch, double* x0, const double* v,
                           int nFree, const int* FreeInitStates, double* J, double* dJdv, void* stream) {
+  OCS_TRACE("ocs_nlp_objective_dev");
   if (!g || !p || !c || !x0 || !v || !J || !dJdv || batch < 1 || nFree < 0 || (nFree > 0 && !FreeInitStates))
     return fail(OCS_ERR_INVALID, "bad argument");
   if (c->nC != p->nC) return fail(OCS_ERR_SHAPE, "control has nC=%d, problem has nC=%d", c->nC, p->nC);
@@ -542,6 +545,7 @@ int ocs_control_set_fusion(ocs_control c, int mode) {
 // host: x0 nS x batch (in/out), v (nV+nFree) x batch, J batch, dJdv (nV+nFree) x batch
 int ocs_nlp_objective(ocs_integrator g, ocs_problem p, ocs_control c, int batch, double* x0, const double* v,
                       int nFree, const int* FreeInitStates, double* J, double* dJdv) {
+  OCS_TRACE("ocs_nlp_objective");
   if (!g || !p || !c || !x0 || !v || !J || !dJdv || batch < 1 || nFree < 0) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_control(c));
   const int nV = c->nC * c->nBasis + nFree;
@@ -557,9 +561,14 @@ int ocs_nlp_objective(ocs_integrator g, ocs_problem p, ocs_control c, int batch,
   HIP_TRY(hipMemcpyAsync(J, c->d_J.p, sizeof(double) * batch, hipMemcpyDeviceToHost, c->stream));
   OCS_TRY(cstage_out(c, c->d_dJdv.d(), dJdv, nV, batch));
   if (nFree > 0) OCS_TRY(cstage_out(c, c->d_x0.d(), x0, p->nS, batch));
+  g->traj_status.assign(batch, 0);
+  int rc = OCS_OK;
   for (int b = 0; b < batch; ++b)
-    if (!std::isfinite(J[b])) return OCS_NUM_NONFINITE;
-  return OCS_OK;
+    if (!std::isfinite(J[b])) {
+      g->traj_status[b] = OCS_NUM_NONFINITE;
+      rc = OCS_NUM_NONFINITE;
+    }
+  return rc;
 }
 
 }  // extern "C"

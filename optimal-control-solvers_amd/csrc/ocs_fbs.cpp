@@ -1,6 +1,9 @@
 // ocs_fbs.cpp -- forward-backward sweep driver (functions/fb_sweep.m, compute_x_lam.m,
 // compute_x_lam_J.m) on the integrator grid, batch-aware: every instance carries its own
 // convergence state, the whole batch advances sweep by sweep until no instance is active.
+#include "ocs_trace.hpp"
+#include <cstdio>
+#include <string>
 #include "ocs_handles.hpp"
 
 #include <algorithm>
@@ -155,6 +158,7 @@ extern "C" {
 // 'pchip' continue their end pieces outside the grid, 'previous' gives NaN before the first sample.
 int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* v, int nq, const double* tq,
                    double* out, int batch, void* stream) {
+  OCS_TRACE("ocs_interp_dev");
   if (!x || !v || !tq || !out || nComp < 1 || n < 2 || nq < 0 || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   if (method != OCS_INTERP_LINEAR && method != OCS_INTERP_PREVIOUS && method != OCS_INTERP_PCHIP)
     return fail(OCS_ERR_UNSUPPORTED, "unknown interpolation method %d", method);
@@ -225,13 +229,90 @@ int ocs_fbs_default_options(ocs_fbs_options* o) {
   return OCS_OK;
 }
 
+// The sweep kernels (costate, control update, ControlChar) are templates over the problem functor; the build-defined
+// LQ problem lives in the matrix-core kernels only (ocs_lq_kernels.hip).  For the sweep it is handed on as the SAME
+// problem written as plugin source -- F, dFdx_times_vec, dFdu_times_vec of ocs_oracle.c / ocs_lq_kernels.hip and the
+// Gen-1 ControlChar of the A9 adapter, u = clamp(-Bu' lam e^{rt} / (2 R), bounds) (make_from_symbolic.m:19-23,111) --
+// compiled once per handle with hipRTC.  Parameter block [r | A | Bu | q | rdiag] as in the registry problem.
+static std::string lq_plugin_source(int nS, int nC) {
+  const int oA = 1, oB = 1 + nS * nS, oq = oB + nS * nC, oR = oq + nS;
+  char buf[4096];
+  snprintf(buf, sizeof(buf), R"SRC(
+__device__ void ocs_F(double t, const double* y, const double* u, OCS_PARAMS p, double* f) {
+  double s = 0.0;
+  for (int i = 0; i < %d; ++i) {
+    double a = 0.0;
+    for (int l = 0; l < %d; ++l) a += p[%d + i + %d * l] * y[l];
+    for (int l = 0; l < %d; ++l) a += p[%d + i + %d * l] * u[l];
+    f[i] = a;
+    s += p[%d + i] * (y[i] * y[i]);
+  }
+  for (int l = 0; l < %d; ++l) s += p[%d + l] * (u[l] * u[l]);
+  f[%d] = exp(-p[0] * t) * s;
+}
+__device__ void ocs_dFdx_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  const double e = exp(-p[0] * t);
+  for (int i = 0; i < %d; ++i) {
+    double a = 0.0;
+    for (int l = 0; l < %d; ++l) a += p[%d + l + %d * i] * v[l];
+    g[i] = a + 2 * e * p[%d + i] * y[i] * v[%d];
+  }
+}
+__device__ void ocs_dFdu_times_vec(double t, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  const double e = exp(-p[0] * t);
+  for (int l = 0; l < %d; ++l) {
+    double a = 0.0;
+    for (int i = 0; i < %d; ++i) a += p[%d + i + %d * l] * v[i];
+    g[l] = a + 2 * e * p[%d + l] * u[l] * v[%d];
+  }
+}
+__device__ void ocs_ControlChar(double t, const double* x, const double* lam, OCS_PARAMS p, const double* lb,
+                                const double* ub, double* u) {
+  const double e = exp(p[0] * t);
+  for (int l = 0; l < %d; ++l) {
+    double a = 0.0;
+    for (int i = 0; i < %d; ++i) a += p[%d + i + %d * l] * lam[i];
+    u[l] = fmin(ub[l], fmax(lb[l], -a * e / (2 * p[%d + l])));
+  }
+}
+)SRC",
+           nS, nS, oA, nS, nC, oB, nS, oq, nC, oR, nS,           // F
+           nS, nS, oA, nS, oq, nS,                                 // dFdx
+           nC, nS, oB, nS, oR, nS,                                 // dFdu
+           nC, nS, oB, nS, oR);                                    // ControlChar
+  return std::string(buf);
+}
+// the problem the sweep kernels run: `p` itself, or for OCS_PROBLEM_LQ its plugin-source twin
+static int sweep_problem(ocs_problem_s* p, ocs_problem_s** out) {
+  *out = p;
+  if (p->functor != Functor::LQ) return OCS_OK;
+  if (p->pmask) return fail(OCS_ERR_UNSUPPORTED, "fb_sweep on the LQ problem: per-trajectory parameters are not supported");
+  if (!p->shadow || p->shadow_version != p->version) {
+    if (p->shadow) {
+      ocs_problem_destroy(p->shadow);
+      p->shadow = nullptr;
+    }
+    const std::string src = lq_plugin_source(p->nS, p->nC);
+    ocs_problem q = nullptr;
+    const int rc = ocs_problem_create_from_source(&q, src.c_str(), p->nS, p->nC, p->par.data(), (int)p->par.size(),
+                                                  p->bounds.data(), 1);
+    if (rc != OCS_OK) return rc;
+    p->shadow = q;
+    p->shadow_version = p->version;
+  }
+  *out = p->shadow;
+  return OCS_OK;
+}
+
 // [x, lam] = compute_x_lam(prob, x0, tspan, u, ...) / [x, lam, J] = compute_x_lam_J(...) on the grid.
 // device: x0 [nS][B], ugrid [2N+1][nC][B] -> xaug [N+1][nAug][B] (states + running objective, the
 // augmented system of compute_x_lam_J.m:6-15), lam [N+1][nS][B], J [B] (may be NULL).
 int ocs_compute_x_lam_dev(ocs_integrator g, ocs_problem p, int batch, const double* x0, const double* ugrid,
                           double* xaug, double* lam, double* J, void* stream) {
+  OCS_TRACE("ocs_compute_x_lam_dev");
   if (!g || !p || !x0 || !ugrid || !xaug || !lam || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   if (g->kind != 0) return fail(OCS_ERR_UNSUPPORTED, "compute_x_lam needs an RK4Integrator grid");
+  OCS_TRY(sweep_problem(p, &p));
   hipStream_t s = (hipStream_t)stream;
   OCS_TRY(bind_problem(g, p, batch, s));
   OCS_TRY(ensure_tables(g));
@@ -264,9 +345,11 @@ int ocs_compute_x_lam_dev(ocs_integrator g, ocs_problem p, int batch, const doub
 int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x0, const ocs_fbs_options* opt,
                      const double* u0grid, const double* u0err, double* xaug, double* lam, double* uInterp,
                      double* J, int* sweeps, double* maxChange, void* stream) {
+  OCS_TRACE("ocs_fb_sweep_dev");
   if (!g || !p || !x0 || !opt || !xaug || !lam || !uInterp || !J || !sweeps || batch < 1)
     return fail(OCS_ERR_INVALID, "bad argument");
   if (g->kind != 0) return fail(OCS_ERR_UNSUPPORTED, "fb_sweep needs an RK4Integrator grid");
+  OCS_TRY(sweep_problem(p, &p));
   if (p->user && !p->user->has_cc)
     return fail(OCS_ERR_UNSUPPORTED, "fb_sweep needs ocs_ControlChar in the user problem source (has_control_char)");
   if (opt->nSWEEPS < 1 || opt->nERROR_PTS < 2 || opt->nINTERP_PTS < 2) return fail(OCS_ERR_INVALID, "bad options");
@@ -528,6 +611,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
 int ocs_fb_sweep(ocs_integrator g, ocs_problem p, int batch, const double* x0, const ocs_fbs_options* opt,
                  const double* u0grid, const double* u0err, double* x, double* lam, double* uInterp, double* J,
                  int* sweeps, double* maxChange) {
+  OCS_TRACE("ocs_fb_sweep");
   if (!g || !p || !x0 || !opt || !x || !lam || !uInterp || !J || !sweeps || batch < 1)
     return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_grid(g));
@@ -597,6 +681,7 @@ int ocs_fb_sweep(ocs_integrator g, ocs_problem p, int batch, const double* x0, c
 // host compute_x_lam(_J): x0 nS x batch, ugrid nC x (2N+1) x batch -> x nS x (N+1) x batch, lam same, J (or NULL)
 int ocs_compute_x_lam(ocs_integrator g, ocs_problem p, int batch, const double* x0, const double* ugrid, double* x,
                       double* lam, double* J) {
+  OCS_TRACE("ocs_compute_x_lam");
   if (!g || !p || !x0 || !ugrid || !x || !lam || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_grid(g));
   OCS_TRY(ensure_tables(g));

@@ -110,6 +110,10 @@ struct ocs_problem_s {
   int pb_batch = 0;
   unsigned long long version = 0;  // bumps whenever device-visible parameters change
   bool uploaded = false;
+  // OCS_PROBLEM_LQ only: the same problem as generated device source (hipRTC), built on first use by the
+  // forward-backward-sweep entry points, whose kernels are instantiated per functor (ocs_fbs.cpp: lq_shadow)
+  ocs_problem_s* shadow = nullptr;
+  unsigned long long shadow_version = 0;
 };
 
 struct ocs_fbs_state;  // forward-backward-sweep workspace (ocs_fbs.cpp)
@@ -120,6 +124,9 @@ struct ocs_integrator_s {
   ocs_fbs_state* fbs = nullptr;
   int rec_stride = 8;  // doubles per step record of the bound problem
   bool uniform = false;  // all steps of the grid have the same size
+  hipEvent_t tc_event = nullptr;   // recorded behind the kernels that build TC / TU / REC / RECS ...
+  hipStream_t tc_stream = nullptr; // ... on this stream: a call on another stream waits for it first
+  std::vector<int> traj_status;    // per-trajectory flags of the last host compute_states / nlp_objective
   int mapping = 0;  // ocs::Mapping requested through ocs_integrator_set_mapping (0 = automatic)
   int kind = 0;  // 0 RK4Integrator, 1 RK4InfiniteIntegrator (then `leg2` and `ustar` are set)
   ocs_integrator_s* leg2 = nullptr;   // integrator2 of RK4InfiniteIntegrator.m:13-14
@@ -232,6 +239,12 @@ inline int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStr
     }
     g->tc_prob = p;
     g->tc_version = p->version;
+    // the tables are valid for every later call on this stream; a call on another stream must wait for them
+    if (!g->tc_event) HIP_TRY(hipEventCreateWithFlags(&g->tc_event, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(g->tc_event, s));
+    g->tc_stream = s;
+  } else if (g->tc_event && s != g->tc_stream) {
+    HIP_TRY(hipStreamWaitEvent(s, g->tc_event, 0));
   }
   return OCS_OK;
 }

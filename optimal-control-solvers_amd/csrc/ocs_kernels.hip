@@ -346,6 +346,15 @@ int launch_to_traj_major(const double* src, double* dst, int per, int batch, hip
   return hip_rc(hipGetLastError());
 }
 
+__global__ void k_traj_status(const double* __restrict__ J, int n, int* __restrict__ status) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) status[i] = isfinite(J[i]) ? 0 : 1;   // OCS_NUM_NONFINITE
+}
+int launch_traj_status(const double* J, int n, int* status, hipStream_t s) {
+  hipLaunchKernelGGL(k_traj_status, dim3((n + 255) / 256), dim3(256), 0, s, J, n, status);
+  return hip_rc(hipGetLastError());
+}
+
 int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s) {
   hipLaunchKernelGGL(k_count_nonfinite, dim3((n + 255) / 256), dim3(256), 0, s, v, n, count);
   return hip_rc(hipGetLastError());

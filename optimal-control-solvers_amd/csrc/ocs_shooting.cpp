@@ -5,6 +5,7 @@
 // bounds of compute_nlp_bounds, non-monotone Armijo back-tracking) in which every instance keeps its own step
 // length, line search and stopping test, and every objective / gradient evaluation is one call of the hot path
 // (nlpObjective, :137-150) over the whole batch.  Iterates differ from fmincon's; the KKT point is the same.
+#include "ocs_trace.hpp"
 #include "ocs_handles.hpp"
 
 #include <limits>
@@ -31,6 +32,7 @@ int ocs_single_shooting_batch_dev(ocs_integrator g, ocs_problem p, ocs_control c
                                   int nFree, const int* FreeInitStates, const double* Lb, const double* Ub,
                                   const ocs_ss_options* opt, double* J, int* iterations, int* converged,
                                   double* pgnorm, void* stream) {
+  OCS_TRACE("ocs_single_shooting_batch_dev");
   if (!g || !p || !c || !x0 || !v || !opt || !J || batch < 1 || nFree < 0) return fail(OCS_ERR_INVALID, "bad argument");
   if (opt->MaxIter < 0 || opt->memory < 1 || opt->maxBacktracks < 1 || !(opt->TolFun > 0))
     return fail(OCS_ERR_INVALID, "bad options");
@@ -39,13 +41,13 @@ int ocs_single_shooting_batch_dev(ocs_integrator g, ocs_problem p, ocs_control c
   OCS_TRY(ocs_control_dims(c, &nB, &nC, &nT));
   const int nV = nB * nC + nFree;
   const size_t B = (size_t)batch, vb = sizeof(double) * (size_t)nV * B;
-  DevBuf gbuf, dbuf, vtbuf, gtbuf, sc, hist, flags, lbub, counter;
+  DevBuf gbuf, dbuf, vtbuf, gtbuf, sc, hist, flags, lbub, counter, conv;
   struct Rel {
-    DevBuf* b[9];
+    DevBuf* b[10];
     ~Rel() {
       for (DevBuf* q : b) q->release();
     }
-  } rel{{&gbuf, &dbuf, &vtbuf, &gtbuf, &sc, &hist, &flags, &lbub, &counter}};
+  } rel{{&gbuf, &dbuf, &vtbuf, &gtbuf, &sc, &hist, &flags, &lbub, &counter, &conv}};
   OCS_TRY(gbuf.ensure(vb));
   OCS_TRY(dbuf.ensure(vb));
   OCS_TRY(vtbuf.ensure(vb));
@@ -114,7 +116,6 @@ int ocs_single_shooting_batch_dev(ocs_integrator g, ocs_problem p, ocs_control c
   }
   // x0 at FreeInitStates follows the last evaluated trial point: make it (and J, g) those of the returned v
   if (nFree > 0) OCS_TRY(ocs_nlp_objective_dev(g, p, c, batch, x0, v, nFree, FreeInitStates, J, a.g, stream));
-  DevBuf conv;
   OCS_TRY(conv.ensure(sizeof(int) * B));
   LAUNCH_TRY(launch_spg(4, a, 0, pgnorm, (int*)conv.p, s));
   std::vector<int> hc(B);
@@ -122,7 +123,6 @@ int ocs_single_shooting_batch_dev(ocs_integrator g, ocs_problem p, ocs_control c
   if (converged) HIP_TRY(hipMemcpyAsync(converged, conv.p, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
   if (iterations) HIP_TRY(hipMemcpyAsync(iterations, a.iters, sizeof(int) * B, hipMemcpyDeviceToDevice, s));
   HIP_TRY(hipStreamSynchronize(s));
-  conv.release();
   for (size_t b = 0; b < B; ++b)
     if (!hc[b]) return OCS_NUM_NOT_CONVERGED;
   return OCS_OK;

@@ -101,21 +101,58 @@ class RK4Integrator(Integrator):
         return (lam, dJdu) if nargout > 1 else lam
 
     # ---- device path (batch-minor torch tensors, async on the current stream) --------
+    @staticmethod
+    def _chk(name, t, shape, dev):
+        """a wrongly sized or misplaced device tensor is an out-of-bounds access inside a kernel, i.e. a GPU fault:
+        check shape, dtype, contiguity and device here"""
+        if t is None:
+            return
+        if tuple(t.shape) != tuple(shape) or t.dtype != torch.float64 or not t.is_contiguous() or t.device != dev:
+            raise ValueError(f"{name}: expected a contiguous float64 tensor of shape {tuple(shape)} on {dev}, "
+                             f"got {tuple(t.shape)} {t.dtype} on {t.device}")
+
     def compute_states_dev(self, prob, x0, u, x=None, J=None):
         """x0 [nS][B], u [2N+1][nC][B] -> x [N+1][nAug][B] (optional), J [B]."""
         N = self.nSTEPS
         B = x0.shape[-1]
+        nS, nC, dev = prob.nS, prob.ControlBounds.shape[0], x0.device
         if J is None:
-            J = torch.empty(B, dtype=torch.float64, device=x0.device)
+            J = torch.empty(B, dtype=torch.float64, device=dev)
+        self._chk("x0", x0, (nS, B), dev)
+        self._chk("u", u, (2 * N + 1, nC, B), dev)
+        self._chk("x", x, (N + 1, nS + 1, B), dev)
+        self._chk("J", J, (B,), dev)
         check(lib.ocs_compute_states_dev(self._h, prob._h, B, _dptr(x0), _dptr(u), _dptr(x), _dptr(J),
                                          _stream()))
+        self._ck_ref = x   # the adjoint pass re-reads it (the xK contract): keep it alive until then
         return x, J
 
     def compute_adjoints_dev(self, prob, u, lamT=None, lam=None, dJdu=None):
+        N = self.nSTEPS
         B = u.shape[-1]
+        nS, nC, dev = prob.nS, prob.ControlBounds.shape[0], u.device
+        self._chk("u", u, (2 * N + 1, nC, B), dev)
+        self._chk("lamT", lamT, (nS + 1, B), dev)
+        self._chk("lam", lam, (N + 1, nS + 1, B), dev)
+        self._chk("dJdu", dJdu, (2 * N + 1, nC, B), dev)
         check(lib.ocs_compute_adjoints_dev(self._h, prob._h, B, _dptr(u), _dptr(lamT), _dptr(lam),
                                            _dptr(dJdu), _stream()))
         return lam, dJdu
+
+    def trajectory_status(self, batch):
+        """per-trajectory flags of the last host compute_states / nlp_objective call on this handle
+        (OCS_NUM_NONFINITE = 1 where the objective is NaN/Inf)"""
+        st = np.zeros(batch, dtype=np.int32)
+        check(lib.ocs_integrator_trajectory_status(self._h, batch, st.ctypes.data_as(C.POINTER(C.c_int))))
+        return st
+
+
+def trajectory_status_dev(J, status=None):
+    """device: status [B] int32 from J [B] (asynchronous on the current stream)"""
+    if status is None:
+        status = torch.empty(J.shape[0], dtype=torch.int32, device=J.device)
+    check(lib.ocs_trajectory_status_dev(J.shape[0], _dptr(J), C.c_void_p(status.data_ptr()), _stream()))
+    return status
 
 
 class RK4InfiniteIntegrator(RK4Integrator):

@@ -31,7 +31,15 @@ def _options(options):
     for k in ("uRelTol", "uAbsTol", "nSWEEPS", "nERROR_PTS", "nINTERP_PTS", "fused_update_off", "nWINDOWS", "cost_row"):
         if k in options:
             setattr(o, k, options[k])
-    # RelTol / AbsTol (fb_sweep.m:18-19) steer odevr7's step control; the grid RK4 has none.
+    # RelTol / AbsTol (fb_sweep.m:18-19) steer odevr7's adaptive step control.  Here the passes are classical RK4 on
+    # the caller's tspan grid: accuracy is set by the grid (4th order, tests/test_oracle_kat.py), not by these
+    # tolerances -- say so instead of ignoring them silently.
+    ignored = [k for k in ("RelTol", "AbsTol") if k in options]
+    if ignored:
+        import warnings
+        warnings.warn(f"fb_sweep: {', '.join(ignored)} steer the reference's adaptive odevr7 integrator and have no effect "
+                      "here: the state/costate passes are fixed-step RK4 on tspan (refine tspan for accuracy)",
+                      RuntimeWarning, stacklevel=3)
     return o, options
 
 

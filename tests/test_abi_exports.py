@@ -64,3 +64,28 @@ def test_host_side_grid_and_argument_validation(pkg):
         with pytest.raises(pkg.OcsError) as e:
             g.compute_states(prob, [1.0], np.zeros((1, 21)))
         assert e.value.code == -4
+
+
+def test_matlab_shims_only_call_exported_symbols(pkg):
+    """matlab/*.m (the reference-side binding, unverifiable without MATLAB): every calllib target must be a symbol the
+    header declares and the library exports, and every shim must subclass / replace what it says it does."""
+    import glob
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    files = sorted(glob.glob(os.path.join(root, "matlab", "*.m")))
+    assert {os.path.basename(f) for f in files} >= {"GpuTestOCProblem.m", "GpuRK4Integrator.m", "GpuPWLinearControl.m",
+                                                    "gpu_fb_sweep.m", "gpu_compute_equilibrium.m", "ocs_check.m",
+                                                    "ocs_load.m", "gpu_nlp_objective.m"}
+    header = open(os.path.join(root, "include", "ocs.h")).read()
+    declared = set(re.findall(r"\b(ocs_[a-z0-9_]+)\s*\(", header))
+    called = set()
+    for f in files:
+        called |= set(re.findall(r"calllib\('libocs',\s*'(ocs_[a-z0-9_]+)'", open(f).read()))
+    assert called and called <= declared, sorted(called - declared)
+    lib = C.CDLL(os.path.join(root, "optimal-control-solvers_amd", "lib", "libocs.so"))
+    for name in called:
+        assert hasattr(lib, name), name
+    assert "classdef GpuRK4Integrator < Integrator" in open(os.path.join(root, "matlab", "GpuRK4Integrator.m")).read()
+    assert "classdef GpuPWLinearControl < Control" in open(os.path.join(root, "matlab", "GpuPWLinearControl.m")).read()
+    assert "classdef GpuTestOCProblem < OCProblem" in open(os.path.join(root, "matlab", "GpuTestOCProblem.m")).read()

@@ -122,6 +122,32 @@ def test_matches_user_plugin_path(ocs):
     assert relerr(xa, xb) < RTOL and relerr(Ja, Jb) < RTOL and relerr(la, lb) < RTOL and relerr(da, db) < RTOL
 
 
+def test_fb_sweep_on_the_lq_problem(ocs, oracle):
+    """fb_sweep.m:79-125 on OCS_PROBLEM_LQ (the registry problem is handed to the sweep kernels as generated plugin
+    source, with the Gen-1 ControlChar u = clamp(-Bu' lam e^{rt} / (2 R))): single instance against the oracle, and a
+    small batch of initial states; compute_x_lam on the same path."""
+    nS, nC, N = 5, 2, 400
+    pg, po = make(ocs, oracle, nS, nC)
+    tspan = oracle.linspace(0, 2.0, N + 1)
+    x0 = np.linspace(0.5, 1.5, nS)
+    opt = {"nERROR_PTS": 401, "nINTERP_PTS": 101, "nSWEEPS": 200}
+    ref = oracle.fb_sweep(po, x0, tspan, opt)
+    assert ref["_sweeps"] > 0
+    soln = ocs.fb_sweep(pg, x0, tspan, opt)
+    assert set(soln) == {"x", "lam", "u", "J"}
+    assert abs(soln["J"] - ref["J"]) < 1e-10 * abs(ref["J"])
+    assert relerr(soln["u"](ref["_interpPts"]), ref["u"]) < 1e-10
+    assert relerr(soln["x"](tspan), ref["x"]) < 1e-10 and relerr(soln["lam"](tspan), ref["lam"]) < 1e-10
+    # a batch of instances differing in x0: instance b equals the single-instance solve
+    X0 = np.stack([x0, 0.5 * x0, -x0], axis=1)
+    sb = ocs.fb_sweep_batch(pg, X0, tspan, opt)
+    assert sb["sweeps"][0] == ref["_sweeps"] and abs(sb["J"][0] - ref["J"]) < 1e-10 * abs(ref["J"])
+    r2 = oracle.fb_sweep(po, -x0, tspan, opt)
+    assert sb["sweeps"][2] == r2["_sweeps"] and abs(sb["J"][2] - r2["J"]) < 1e-10 * abs(r2["J"])
+    # the quadratic objective is even in x0 (u -> -u, bounds symmetric): J(x0) == J(-x0) to round-off
+    assert abs(sb["J"][0] - sb["J"][2]) < 1e-10 * abs(ref["J"])
+
+
 def test_unsupported_shapes_fail_loudly(ocs):
     A, Bu, q, rdiag = lq_matrices(33, 2)
     with pytest.raises(Exception):

@@ -181,6 +181,34 @@ def test_nonfinite_status(ocs):
     assert g.status == 1  # OCS_NUM_NONFINITE
 
 
+def test_per_trajectory_status_and_tracing(ocs):
+    # a status word per trajectory (the global OCS_NUM_NONFINITE says only "some"), host and device forms;
+    # roctx ranges around the entry points when a marker library is present (it is on this image)
+    import torch
+    pg = ocs.TestOCProblem(P, BOUNDS)
+    g = ocs.RK4Integrator(np.linspace(0, 10, 21))      # h = 0.5: RK4 overflows from x0 = 50, is stable from x0 = 1
+    x0 = np.array([[50.0, 1.0, 50.0, 1.0, 1.0]])
+    _, J = g.compute_states(pg, x0, np.zeros((1, 41, 5)))
+    assert g.status == 1
+    st = g.trajectory_status(5)
+    assert list(st) == [1, 0, 1, 0, 0] and list(~np.isfinite(J)) == [True, False, True, False, False]
+    Jd = torch.tensor(J, device="cuda:0")
+    std = ocs.trajectory_status_dev(Jd)
+    torch.cuda.synchronize()
+    assert std.cpu().tolist() == [1, 0, 1, 0, 0]
+    with pytest.raises(ocs.OcsError):
+        g.trajectory_status(7)                         # no call with that batch
+    assert ocs.tracing_enabled()
+    # device wrappers refuse wrongly shaped / placed tensors instead of faulting on the GPU
+    xd = torch.empty((21, 2, 5), dtype=torch.float64, device="cuda:0")
+    with pytest.raises(ValueError):
+        g.compute_states_dev(pg, torch.ones((1, 5), dtype=torch.float64, device="cuda:0"),
+                             torch.zeros((40, 1, 5), dtype=torch.float64, device="cuda:0"), xd)
+    with pytest.raises(ValueError):
+        g.compute_states_dev(pg, torch.ones((1, 5), dtype=torch.float64), torch.zeros((41, 1, 5), dtype=torch.float64,
+                                                                                        device="cuda:0"), xd)
+
+
 def test_blow_up_trajectories_agree(ocs, oracle):
     # harvest above the maximum sustainable yield of the m = 1.5 state: x -> -inf, then NaN.
     # Overflow happens at the same step on both sides; finite entries still meet the tolerance.
