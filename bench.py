@@ -11,9 +11,12 @@ batch * N fused RK4 state+costate steps.  Inputs are synthetic and already resid
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
          --master-port P bench.py --gpus N --steps K --warmup W
 
-Multi-GPU: the batch axis shards with no data-path exchange (weak scaling, 4096 per GPU); the
-only collective is the all-reduce(SUM) of the objective sum over ranks (north_star), 8 bytes per step,
-issued asynchronously so that it overlaps the next step's kernels.
+Multi-GPU: the batch axis shards with no data-path exchange; the only collective is the all-reduce(SUM) of the
+objective sum over ranks (north_star), 8 bytes per step, issued asynchronously so that it overlaps the next step's
+kernels.  --scaling weak (default): 4096 trajectories per GPU; --scaling strong: --batch is the TOTAL, split into
+contiguous blocks.  The secondary legs shard as BASELINE.json names them: configs[3] (65 536 Chebyshev candidates,
+8192 per GPU at N = 8, J all-gathered, best candidate selected) and configs[4] (8192 LQ32 trajectories, 1024 per GPU
+at N = 8); fb_sweep (configs[2]) shards its 16 384 instances the same way.  Every rank runs every leg.
 """
 import argparse
 import json
@@ -49,8 +52,9 @@ def make_inputs(batch, device, seed):
 
 
 def cpu_baseline(tspan, x0, u, target_seconds=12.0):
-    """Times the CPU oracle (the C restatement of RK4Integrator.m, OpenMP over the batch) on the
-    same workload: kind 'port'.  Bounded: repeats whole-batch passes until ~target_seconds."""
+    """Times the CPU oracle (the C restatement of RK4Integrator.m) on the same workload, kind 'port': (a) OpenMP over
+    the batch on all host cores, whole-batch passes for ~target_seconds; (b) one thread, on the first 256
+    trajectories of the same batch for ~4 s (SURVEY 8(d) asks for both)."""
     from oracle import oracle as orc
     orc.build()
     try:
@@ -76,10 +80,34 @@ def cpu_baseline(tspan, x0, u, target_seconds=12.0):
         if dt >= target_seconds or passes >= 200:
             break
     batch = x0.shape[1]
+    # one thread
+    b1 = min(256, batch)
+    x1, u1 = np.ascontiguousarray(x0[:, :b1]), np.asfortranarray(u_m[:, :, :b1])
+    o1 = orc.batch_states_adjoints(prob, tspan, x1, u1, nthreads=1)
+    t1 = time.perf_counter()
+    p1 = 0
+    while True:
+        orc.batch_states_adjoints(prob, tspan, x1, u1, nthreads=1, out=o1)
+        p1 += 1
+        d1 = time.perf_counter() - t1
+        if d1 >= 4.0 or p1 >= 200:
+            break
     return {"value": batch * NSTEPS * passes / dt, "unit": "RK4 state+costate steps/s", "cores": cores,
             "kind": "port",
             "sample": f"{passes} full passes of the bench workload (batch {batch} x {NSTEPS} steps, "
-                      f"x/J/lam/dJdu written) in {dt:.1f} s, oracle/ocs_oracle.c with OpenMP over the batch"}, out
+                      f"x/J/lam/dJdu written) in {dt:.1f} s, oracle/ocs_oracle.c with OpenMP over the batch",
+            "one_thread": {"value": b1 * NSTEPS * p1 / d1, "unit": "RK4 state+costate steps/s", "cores": 1,
+                           "sample": f"{p1} passes over the first {b1} trajectories of the same batch in {d1:.1f} s"}}, out
+
+
+def _shard(ocs, total):
+    world, rank = ocs.distributed.world_info()
+    lo, hi = ocs.distributed.shard_bounds(total, world, rank)
+    return world, rank, lo, hi
+
+
+def _sync():
+    torch.cuda.synchronize()
 
 
 def fb_sweep_metric(ocs, dev, batch=16384, reps=3):
@@ -87,54 +115,125 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=3):
     TestOCProblem through the A9 adapter, T=10, N=1000 forward + 1000 backward, batch=16384 instances with
     x0 ~ U(0.5,2.5), c ~ U(1,2) (seed 20260402), u0 = lower bound, default tolerances, <= 50 sweeps.
     One iter = forward + costate + control update + convergence reduction for one instance; converged
-    instances stop counting (the whole batch still runs until the last one is done)."""
+    instances stop counting (the whole batch still runs until the last one is done).  Under world > 1 the instances
+    shard into contiguous blocks (no exchange; the count of iterations is all-reduced)."""
+    world, rank, lo, hi = _shard(ocs, batch)
     rng = np.random.default_rng(20260402)
     tspan = ocs.linspace(0.0, T_END, NSTEPS + 1)  # MATLAB's linspace, as fb_sweep.m:69-70 builds its point sets
-    x0 = torch.tensor(rng.uniform(0.5, 2.5, (1, batch)), device=dev)
-    cs = rng.uniform(1.0, 2.0, batch)
+    x0 = torch.tensor(np.ascontiguousarray(rng.uniform(0.5, 2.5, (1, batch))[:, lo:hi]), device=dev)
+    cs = rng.uniform(1.0, 2.0, batch)[lo:hi]
     prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
     prob.set_batch_params([0], cs[None, :])
     integ = ocs.RK4Integrator(tspan)
     ocs.fb_sweep_dev(prob, integ, x0)  # warm-up (allocations, tables)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        r = ocs.fb_sweep_dev(prob, integ, x0)
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
-    sw = r["sweeps"].cpu().numpy()
-    iters = int(np.where(sw > 0, sw, 50).sum())
+    res = {}
+
+    def solve():
+        res["r"] = ocs.fb_sweep_dev(prob, integ, x0)
+    dt = ocs.distributed.timed_max_over_ranks(solve, reps, _sync)
+    sw = res["r"]["sweeps"].cpu().numpy()
+    tot = torch.tensor([float(np.where(sw > 0, sw, 50).sum()), float((sw > 0).sum()), float(sw.max())],
+                       dtype=torch.float64, device=dev)
+    if world > 1:
+        import torch.distributed as dist
+        mx = tot[2:].clone()
+        dist.all_reduce(tot[:2])
+        dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+        tot[2] = mx[0]
+    iters, nconv, smax = float(tot[0]), float(tot[1]), float(tot[2])
+    # algorithmic bytes per (instance, step) of one sweep: x write + read, lam write, u read twice, u write
+    # = 8 (3 nS + 6 nC) = 72 B (SURVEY 8(d)); a "batch sweep" moves that for every instance of the (local) batch
+    bytes_sweep = 72.0 * (hi - lo) * NSTEPS
+    bsps = float(sw.max()) / dt
     return {"value": iters / dt, "unit": "fb_sweep iters/s (instance-sweeps)", "batch": batch, "n_steps": NSTEPS,
-            "seconds_per_solve": dt, "sweeps_min": int(sw[sw > 0].min()) if (sw > 0).any() else 0,
-            "sweeps_max": int(sw.max()), "fraction_converged": float((sw > 0).mean()),
-            "batch_sweeps_per_s": float(sw.max()) / dt}
+            "batch_per_gpu": hi - lo, "seconds_per_solve": dt,
+            "sweeps_min": int(sw[sw > 0].min()) if (sw > 0).any() else 0,
+            "sweeps_max": int(smax), "fraction_converged": nconv / batch,
+            "batch_sweeps_per_s": bsps,
+            "roofline": {"bound": "hbm", "kernel": "one sweep of the local batch: forward k_forward_p2 + costate "
+                                                   "k_costate_plx + control update k_control_grid + bookkeeping",
+                         "achieved": bytes_sweep * bsps / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": bytes_sweep * bsps / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+                         "algorithmic_bytes_per_batch_sweep": bytes_sweep}}
 
 
 def bl4_metric(ocs, dev, batch=65536, reps=5):
     """BASELINE configs[3] (SURVEY BL-4): single_shooting objective + gradient (single_shooting.m:137-150) with a
-    Chebyshev basis of 16 coefficients, TestOCProblem, N = 1000, batch = 65536 coefficient vectors (seed 20260403).
-    One evaluation = u = v*B, forward, adjoint, dJdv = dJdu*B' for the whole batch."""
+    Chebyshev basis of 16 coefficients, TestOCProblem, N = 1000, batch = 65536 coefficient vectors (seed 20260403),
+    sharded into contiguous blocks (8192 per GPU at 8 GPUs) through distributed.sharded_objective_eval: one evaluation
+    = u = v*B, forward, adjoint, dJdv = dJdu*B' for the local block, then the all-gather of J, the best candidate and
+    the ensemble mean (the only collectives; KBs)."""
+    world, rank, lo, hi = _shard(ocs, batch)
     rng = np.random.default_rng(20260403)
     V = 0.05 * rng.normal(size=(16, batch)) / np.arange(1, 17)[:, None]
     V[0] += 0.5
     integ = ocs.RK4Integrator(np.linspace(0.0, T_END, NSTEPS + 1))
     prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
     ctrl = ocs.ChebyshevControl(integ.t, 16, 1)
-    vd = torch.tensor(V, device=dev)
-    x0 = torch.ones((1, batch), dtype=torch.float64, device=dev)
-    J = torch.empty(batch, dtype=torch.float64, device=dev)
-    G = torch.empty_like(vd)
+    Vg = torch.tensor(V, device=dev)
+    nloc = hi - lo
+    x0 = torch.ones((1, nloc), dtype=torch.float64, device=dev)
+    J = torch.empty(nloc, dtype=torch.float64, device=dev)
+    G = torch.empty((16, nloc), dtype=torch.float64, device=dev)
+
+    def eval_local(Vl):
+        ocs.nlp_objective_dev(integ, prob, ctrl, x0, Vl, (), J, G)
+        return J, G
+    out = {}
+    Vl = Vg[:, lo:hi].contiguous()
+
+    def one():
+        out["r"] = ocs.distributed.sharded_objective_eval(eval_local, Vg)
     for _ in range(2):
-        ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
+        one()
+    # `value`: the evaluations themselves (the data path), barrier-bracketed, max over ranks; the KB-size
+    # post-reductions (J all-gather, best candidate, ensemble mean; each ends in a host read) are timed with them
+    # once more and reported beside it
+    dt = ocs.distributed.timed_max_over_ranks(lambda: eval_local(Vl), reps, _sync)
+    dt_red = ocs.distributed.timed_max_over_ranks(one, reps, _sync)
+    r = out["r"]
+    # objective+gradient-only mode: the checkpoint of every step is written once and read once, 8*2*nAug = 32 B
+    # per (trajectory, step) (SURVEY 8(d)); u and dJdu never reach memory (fused Chebyshev basis)
+    bytes_eval = 32.0 * nloc * NSTEPS
+    return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s inside objective+gradient evaluations",
+            "batch": batch, "batch_per_gpu": nloc, "n_basis": 16, "ms_per_batch_evaluation": dt * 1e3,
+            "evaluations_per_s": batch / dt, "finite": bool(torch.isfinite(G).all().item()),
+            "ms_per_evaluation_with_post_reductions": dt_red * 1e3,
+            "best_candidate": {"J": r["best"][0], "index": r["best"][1]}, "J_all_gathered": int(r["J_all"].numel()),
+            "roofline": {"bound": "hbm (serial-chain bound at this batch: 1024 waves, one per SIMD)",
+                         "kernel": "k_forward_fc + k_backward_fc (fused Chebyshev basis), local block",
+                         "achieved": bytes_eval / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": bytes_eval / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+                         "algorithmic_bytes_per_evaluation": bytes_eval}}
+
+
+def bl2_large_batch_metric(ocs, dev, batch=65536, reps=5):
+    """The BL-2 problem in the HBM-bound regime (the lane-per-trajectory mapping at batch 65 536, full output): the
+    figure DESIGN.md quotes for "what the passes reach once the chip is full"."""
+    tspan, x0_h, u_h = make_inputs(batch, dev, 20260409)
+    prob = ocs.LogisticProblem(M, C_PAR, R_PAR, [[0.0, 1.0]])
+    integ = ocs.RK4Integrator(tspan).set_mapping("lane")
+    x0, u = torch.tensor(x0_h, device=dev), torch.tensor(u_h, device=dev)
+    x = torch.empty((NSTEPS + 1, NS + 1, batch), dtype=torch.float64, device=dev)
+    lam, dJdu = torch.empty_like(x), torch.empty_like(u)
+    J = torch.empty(batch, dtype=torch.float64, device=dev)
+
+    def pair():
+        integ.compute_states_dev(prob, x0, u, x, J)
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+    pair()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(reps):
-        ocs.nlp_objective_dev(integ, prob, ctrl, x0, vd, (), J, G)
+        pair()
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
-    return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s inside objective+gradient evaluations",
-            "batch": batch, "n_basis": 16, "ms_per_batch_evaluation": dt * 1e3,
-            "evaluations_per_s": batch / dt, "finite": bool(torch.isfinite(G).all().item())}
+    nbytes = 8.0 * (3 * (NS + 1) + 6 * NC) * batch * NSTEPS
+    return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "mapping": "lane",
+            "ms_per_pass_pair": dt * 1e3,
+            "roofline": {"bound": "hbm", "kernel": "k_forward + k_backward (lane per trajectory), pass pair",
+                         "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None}}
 
 
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (= fp64 vector peak), public spec
@@ -143,8 +242,12 @@ FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (= fp64 vector peak), p
 def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2):
     """BASELINE configs[4] (SURVEY BL-5): build-defined LQ32 (nS = 32, nC = 4, A = -diag(logspace(0,3,32)) + 0.1 G,
     seed 20260405), RK4InfiniteIntegrator with N2 = N = 4000 tail steps (|lambda_max| h = 2.5), uStar = 0,
-    batch 8192 per GPU, full output.  The stage products A*Y / A'*k run on v_mfma_f64_16x16x4_f64
-    (csrc/ocs_lq_kernels.hip); fp64-compute-bound, so the roofline is the fp64 matrix peak."""
+    batch 8192 in total (sharded: 1024 per GPU at 8 GPUs -- 64 groups of 16 trajectories, i.e. 128 waves of the
+    two-wave kernels on 1024 SIMDs: that leg is latency-bound by design of the config), full output.  The stage
+    products A*Y / A'*k run on v_mfma_f64_16x16x4_f64 (csrc/ocs_lq_kernels.hip); fp64-compute-bound, so the roofline
+    is the fp64 matrix peak."""
+    world, rank, lo, hi = _shard(ocs, batch)
+    nloc = hi - lo
     nS, nC, T = 32, 4, 10.0
     rng = np.random.default_rng(20260405)
     A = -np.diag(np.logspace(0, 3, nS)) + 0.1 * rng.normal(size=(nS, nS))
@@ -153,10 +256,10 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2):
     prob = ocs.LQProblem(A, Bu, q, rd, 0.05, [[-1.0, 1.0]] * nC)
     N = nsteps
     integ = ocs.RK4InfiniteIntegrator(np.linspace(0, T, N + 1), np.linspace(T, 2 * T, N + 1), np.zeros(nC))
-    g = torch.Generator(device=dev).manual_seed(20260405)
-    u = torch.rand((2 * N + 1, nC, batch), dtype=torch.float64, device=dev, generator=g) * 2 - 1
-    x0 = torch.randn((nS, batch), dtype=torch.float64, device=dev, generator=g)
-    x = torch.empty((N + 1, nS + 1, batch), dtype=torch.float64, device=dev)
+    g = torch.Generator(device=dev).manual_seed(20260405 + rank)
+    u = torch.rand((2 * N + 1, nC, nloc), dtype=torch.float64, device=dev, generator=g) * 2 - 1
+    x0 = torch.randn((nS, nloc), dtype=torch.float64, device=dev, generator=g)
+    x = torch.empty((N + 1, nS + 1, nloc), dtype=torch.float64, device=dev)
     lam = torch.empty_like(x)
     dJdu = torch.empty_like(u)
     _, J = integ.compute_states_dev(prob, x0, u, x)
@@ -173,19 +276,26 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2):
         torch.cuda.synchronize()
         tf += ev[0].elapsed_time(ev[1]) * 1e-3 / reps
         tb += ev[1].elapsed_time(ev[2]) * 1e-3 / reps
-    steps = batch * 2 * N                    # RK4 steps of both legs (main + tail)
+
+    def pair():
+        integ.compute_states_dev(prob, x0, u, x, J)
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+    dt = ocs.distributed.timed_max_over_ranks(pair, reps, _sync)      # whole job: barrier, max over ranks
+    steps_local = nloc * 2 * N                # RK4 steps of both legs (main + tail) on this rank
     # algorithmic flops per (trajectory, step): 4 F + 3 recomputed F + 4 A'k products of 2 nS^2, the Bu u / Bu' k
     # products, O(nS) axpys not counted (12 mat-vecs, here 11 because F4 is not needed in the adjoint)
     fl_fwd = 4 * 2 * nS * nS + 3 * 2 * nS * nC
     fl_bwd = 7 * 2 * nS * nS + 2 * 2 * nS * nC + 2 * 2 * nS * nC
-    tfl_b = steps * fl_bwd / tb / 1e12
-    return {"value": steps / (tf + tb), "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
-            "batch": batch, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3, "ms_adjoint": tb * 1e3,
-            "roofline": {"bound": "mfma", "kernel": "k_lq2_backward (adjoint + dJdu, both legs; two waves per 16 trajectories)",
+    tfl_b = steps_local * fl_bwd / tb / 1e12
+    return {"value": batch * 2 * N / dt, "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
+            "batch": batch, "batch_per_gpu": nloc, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3,
+            "ms_adjoint": tb * 1e3, "ms_pass_pair_max_over_ranks": dt * 1e3,
+            "roofline": {"bound": "mfma", "kernel": "k_lq2_backward (adjoint + dJdu, both legs; two waves per 16 "
+                                                    "trajectories), this rank",
                          "achieved": tfl_b, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tfl_b / FP64_MFMA_PEAK_TFLOPS, "traffic": None,
+                         "frac": tfl_b / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "traffic_source": None,
                          "algorithmic_flops_per_trajectory_step": fl_bwd},
-            "pass_pair_TFLOPs": steps * (fl_fwd + fl_bwd) / (tf + tb) / 1e12,
+            "pass_pair_TFLOPs": steps_local * (fl_fwd + fl_bwd) / (tf + tb) / 1e12,
             "finite": bool(torch.isfinite(lam[0]).all().item()) and bool(torch.isfinite(J).all().item())}
 
 
@@ -194,9 +304,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=BATCH, help="trajectories per GPU (default: BASELINE config)")
+    ap.add_argument("--batch", type=int, default=BATCH,
+                    help="trajectories per GPU (weak scaling, default: BASELINE config) / in total (strong scaling)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch per GPU (the driver's contract); strong: --batch is the total, split over the GPUs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-fb-sweep", action="store_true", help="skip the secondary fb_sweep iters/sec measurement")
+    ap.add_argument("--no-fb-sweep", action="store_true", help="skip the secondary legs (fb_sweep, BL-4, BL-5, large batch)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -216,7 +329,11 @@ def main():
     import __graft_entry__ as ge
     ocs = ge.load_package()  # raises if libocs.so is missing: no fallback path
 
-    batch = args.batch
+    if args.scaling == "strong":
+        lo, hi = ocs.distributed.shard_bounds(args.batch, world, rank)
+        batch, total_batch = hi - lo, args.batch
+    else:
+        batch, total_batch = args.batch, args.batch * world
     tspan, x0_h, u_h = make_inputs(batch, dev, 20260401 + rank)
     prob = ocs.LogisticProblem(M, C_PAR, R_PAR, [[0.0, 1.0]])
     integ = ocs.RK4Integrator(tspan)
@@ -261,8 +378,7 @@ def main():
         one_step(k, k)
     drain()
     torch.cuda.synchronize()
-    # (HIP event records between the kernels cost a few us of GPU idle time each, so the timed steps below carry none;
-    #  replaying the two kernels from a captured graph was measured slower than plain stream launches: 222 vs 209 us)
+    # (HIP event records between the kernels cost a few us of GPU idle time each, so the timed steps below carry none)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -287,15 +403,21 @@ def main():
     bytes_bwd = 8 * (2 * nA + 4 * NC) * batch * NSTEPS       # read x, write lam, read u, write dJdu
     ok = bool(torch.isfinite(J).all().item()) and bool(torch.isfinite(dJdu).all().item())
 
+    line = None
     if rank == 0:
-        steps_total = world * batch * NSTEPS * args.steps
-        traffic = None
+        steps_total = total_batch * NSTEPS * args.steps
+        # HBM bytes per launch of the dominant kernel from rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate
+        # passes, calibrated as MI355X_MICROARCH.md prescribes); NOT measured by this run: replayed from the named
+        # profile of the same kernels, or null
+        traffic, traffic_source = None, None
         tr_path = os.path.join(ROOT, "profiles", "traffic_latest.json")
         if os.path.exists(tr_path):
             try:
                 tr = json.load(open(tr_path))
                 if tr.get("batch") == batch and tr.get("kernel") == "k_backward":
                     traffic = tr.get("hbm_bytes_per_launch")
+                    traffic_source = (f"{tr.get('source')} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of these kernels; "
+                                      "replayed from that file, not collected by this run)")
             except Exception:
                 traffic = None
         line = {
@@ -307,22 +429,24 @@ def main():
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": args.scaling,
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "config": {"workload": "BL-2: LogisticK nS=4 (nAug=5, nC=1), 1000 RK4 steps, "
                                    f"batch={batch} control candidates per GPU, full output (x,J,lam,dJdu)",
                        "problem": "LogisticK(m=[3,2.5,2,1.5], c=1.5, r=0.05)", "n_steps": NSTEPS,
-                       "batch_per_gpu": batch, "parallelism": f"batch-sharded x{world}",
-                       "mapping": "automatic (batch <= 8192: wave-specialised pipeline, one state row per lane)"},
-            "roofline": {"bound": "hbm", "kernel": "k_backward_pl (compute_adjoints + compute_dJdu; at this batch the "
-                                                   "wave-specialised kernel)",
+                       "batch_per_gpu": batch, "batch_total": total_batch, "parallelism": f"batch-sharded x{world}",
+                       "mapping": "automatic: compute_states k_forward_p2 (wave-specialised, minimal recursion wave), "
+                                  "compute_adjoints k_backward_scan (scan over time)"},
+            "roofline": {"bound": "hbm", "kernel": "k_backward_scan (compute_adjoints + compute_dJdu)",
                          "achieved": bytes_bwd / t_bwd / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": bytes_bwd / t_bwd / 1e9 / HBM_PEAK_GBPS, "traffic": traffic,
+                         "traffic_source": traffic_source,
                          "algorithmic_bytes_per_launch": bytes_bwd, "avg_launch_s": t_bwd},
             "kernels": {"k_forward": {"avg_s": t_fwd, "alg_bytes": bytes_fwd,
-                                      "GBps": bytes_fwd / t_fwd / 1e9},
+                                      "GBps": bytes_fwd / t_fwd / 1e9,
+                                      "bound": "dependent chain of the state recursion (8 fp64 operations per step)"},
                         "k_backward": {"avg_s": t_bwd, "alg_bytes": bytes_bwd,
                                        "GBps": bytes_bwd / t_bwd / 1e9},
                         # the pass pair over the timed (event-free) steps of this rank
@@ -330,11 +454,19 @@ def main():
                         "pass_pair_frac": (bytes_fwd + bytes_bwd) * args.steps / dt / 1e9 / HBM_PEAK_GBPS},
             "finite": ok,
         }
-        if not args.no_fb_sweep:
-            line["fb_sweep"] = fb_sweep_metric(ocs, dev)
-            line["other_configs"] = {
-                "BL-4 chebyshev16 objective+gradient": bl4_metric(ocs, dev),
-                "BL-5 LQ32 + RK4InfiniteIntegrator (matrix cores)": bl5_metric(ocs, dev)}
+    # secondary legs: every rank runs them on its shard (collectives inside)
+    if not args.no_fb_sweep:
+        fb = fb_sweep_metric(ocs, dev)
+        b4 = bl4_metric(ocs, dev)
+        b5 = bl5_metric(ocs, dev)
+        big = bl2_large_batch_metric(ocs, dev) if world == 1 else None
+        if rank == 0:
+            line["fb_sweep"] = fb
+            line["other_configs"] = {"BL-4 chebyshev16 objective+gradient": b4,
+                                     "BL-5 LQ32 + RK4InfiniteIntegrator (matrix cores)": b5}
+            if big:
+                line["other_configs"]["BL-2 problem at batch 65536 (lane mapping, HBM-bound regime)"] = big
+    if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             cb, ref = cpu_baseline(tspan, x0_h, u_h)
             line["cpu_baseline"] = cb
@@ -343,6 +475,7 @@ def main():
             line["parity_J_max_rel_err_vs_oracle"] = err
         print(json.dumps(line), flush=True)
     if world > 1:
+        dist.barrier()
         dist.destroy_process_group()
 
 

@@ -1233,6 +1233,9 @@ int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const
   return hip_rc5(hipGetLastError());
 }
 
+// (k_costate_pl / k_costate_plx move no control samples: they are only instantiated for registry problems whose
+//  dFdx_times_vec does not read u -- LogisticK -- which pipeline_supported() guarantees; a functor whose adjoint
+//  right-hand side reads u must take launch_costate's lane kernel)
 bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch) {
   return pipeline_supported(f, nS, nC) && N >= 8 && N % 8 == 0 && batch % (64 / nS) == 0;
 }

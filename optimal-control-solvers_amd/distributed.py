@@ -68,3 +68,54 @@ def gather_objectives(J_local: torch.Tensor, total: int):
     out = [torch.empty_like(pad) for _ in range(world)]
     dist.all_gather(out, pad)
     return torch.cat([o[: h - l] for o, (l, h) in zip(out, sizes)])
+
+
+def sharded_objective_eval(eval_local, V_global: torch.Tensor, want_gradient_mean: bool = True):
+    """One sharded objective+gradient evaluation of a global batch of candidates (BASELINE config 4: 65 536
+    coefficient vectors over 8 GPUs): every rank evaluates its contiguous block of columns of V_global [nV][total]
+    with `eval_local(V_local) -> (J_local [B_loc], dJdv_local [nV][B_loc])` -- no data-path exchange -- and the
+    O(1)-size post-reductions follow: all-gather of J (gather_objectives), best candidate (best_candidate), ensemble
+    mean of J and dJdv (ensemble_objective).  bench.py drives the GPU kernels through this function and
+    tests/test_distributed_gloo.py the CPU oracle (gloo), so the sharding / argument path is the same code.
+    Returns dict(lo, hi, J_local, dJdv_local, J_all, best=(Jmin, argmin), J_mean, dJdv_mean)."""
+    world, rank = world_info()
+    total = V_global.shape[1]
+    lo, hi = shard_bounds(total, world, rank)
+    V_local = V_global[:, lo:hi].contiguous()
+    J_local, G_local = eval_local(V_local)
+    out = {"lo": lo, "hi": hi, "J_local": J_local, "dJdv_local": G_local}
+    out["J_all"] = gather_objectives(J_local, total)
+    out["best"] = best_candidate(J_local, lo)
+    Jm, Gm = ensemble_objective(J_local, G_local if want_gradient_mean else None)
+    out["J_mean"], out["dJdv_mean"] = Jm, Gm
+    return out
+
+
+def timed_max_over_ranks(fn, reps: int, sync=None):
+    """Wall time of `reps` calls of fn(), bracketed by a barrier and `sync()` on both sides, maximum over ranks
+    (the contract bench.py's headline loop follows)."""
+    import time
+    world, _ = world_info()
+    if sync:
+        sync()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    if sync:
+        sync()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=_reduce_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt / reps
+
+
+def _reduce_device():
+    if dist.get_backend() == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")

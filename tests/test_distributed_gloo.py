@@ -46,6 +46,19 @@ def _worker(rank, world, port, total, q):
     Jm, Gm = ocs.distributed.ensemble_objective(Jt, Gt)
     best = ocs.distributed.best_candidate(Jt, lo)
     allJ = ocs.distributed.gather_objectives(Jt, total)
+
+    # the driver bench.py uses for BASELINE config 4 under world > 1 (here with the oracle as the per-shard evaluator)
+    def eval_local(Vl):
+        Jl = np.empty(Vl.shape[1])
+        Gl = np.empty((11, Vl.shape[1]))
+        for k in range(Vl.shape[1]):
+            Jl[k], Gl[:, k], _ = orc.nlp_objective(go, po, co, [1.0], Vl[:, k].numpy())
+        return torch.tensor(Jl), torch.tensor(Gl)
+    r = ocs.distributed.sharded_objective_eval(eval_local, torch.tensor(V))
+    assert (r["lo"], r["hi"]) == (lo, hi) and torch.equal(r["J_all"], allJ) and r["best"] == best
+    assert abs(float(r["J_mean"]) - float(Jm)) < 1e-15 and torch.allclose(r["dJdv_mean"], Gm, rtol=0, atol=1e-15)
+    dt = ocs.distributed.timed_max_over_ranks(lambda: None, 3)
+    assert dt >= 0.0
     if rank == 0:
         q.put((float(Jm), Gm.numpy(), best, allJ.numpy(), (lo, hi)))
     dist.barrier()
