@@ -1,3 +1,6 @@
+"""Steady-state loop timings: K forwards back to back, K adjoints back to back, K pairs (MAPPING=auto|pipeline|scan|lane,
+OCS_FWD_V1=1 for the previous state kernel).  The pair is what bench.py times; the difference to the sum of the two
+single-kernel loops is the interference between the kernels (cache write-back, clocks)."""
 import os, sys, time, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import __graft_entry__ as g

@@ -14,13 +14,13 @@ for f in glob.glob(os.path.join(src, "pass*", "**", "*counter_collection.csv"), 
             key = next((w for w in want if w in name), None)
             if not key:
                 continue
-            short = name.split("(")[0].split("<")[0].split("::")[-1]
+            short = name.split("(ocs::")[0].replace("void ", "").replace("ocs::", "").replace(" ", "")
             acc.setdefault(short, {}).setdefault(row["Counter_Name"], []).append(float(row["Counter_Value"]))
 dur = {}
 for f in glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True):
     with open(f) as fh:
         for row in csv.DictReader(fh):
-            short = row["Name"].split("(")[0].split("<")[0].split("::")[-1]
+            short = row["Name"].split("(ocs::")[0].replace("void ", "").replace("ocs::", "").replace(" ", "")
             dur[short] = {"calls": int(row["Calls"]), "avg_us": float(row["AverageNs"]) / 1e3}
 out = {"tag": tag, "note": "mean per dispatch; SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* in quad-cycles summed over waves", "kernels": {}}
 for k, c in sorted(acc.items()):
