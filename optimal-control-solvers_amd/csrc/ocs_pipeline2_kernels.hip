@@ -20,7 +20,7 @@
 //   wave J    prefix-sums the objective increments of the block before that, stores the cost row and J.
 //
 // One LDS-only barrier per block of D = 8 steps.  Interval k (between barriers k and k+1):
-//   M/P: waits for block k+1, prepares it, (barrier), issues block k+1+Q      S: block k      C: block k-1    J: block k-2
+//   M: issues block k+1+Q, waits for block k+2    P: prepares block k+1    S: block k    C: block k-1    J: block k-2
 // Results: the arithmetic of a step is that of k_forward_pl (same formulas, same association) -- the recursion on
 // z and the objective summed over rows before the quadrature weights (Numerics) -- to round-off the
 // lane kernels' and the oracle's.
@@ -93,7 +93,7 @@ struct P2Cfg {
   static constexpr int NCW = (G == 4) ? 2 : 4;       // objective/store waves
   static constexpr int SPW = D / NCW;                // steps per such wave and block
   static constexpr int NPASS = SPW / G > 0 ? SPW / G : 1;
-  static constexpr int NWAVE = 3 + NCW;              // M/P, S, C.., J
+  static constexpr int NWAVE = 4 + NCW;              // M, S, C.., J, P
   static_assert(REC_DBL % 128 == 0 && U_DBL % 128 == 0 && (SPW % G == 0 || G > SPW), "block shapes");
 };
 
@@ -123,7 +123,8 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
   constexpr int NCW = C_::NCW, SPW = C_::SPW;
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];   // {records | u}
   __shared__ __attribute__((aligned(16))) double zb[2][D][64];            // z_i at the start of a step, per S lane
-  __shared__ double ufirst[3][TPW];                                       // control sample at the first node of a block
+  __shared__ double ufirst[4][TPW];
+  __shared__ __attribute__((aligned(16))) double2 prep[2][D][64];        // (cM, cB) of a step, per S lane (wave P -> S)                                       // control sample at the first node of a block
   __shared__ double dd[2][D][TPW];                                        // objective increments of a block
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -151,23 +152,26 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     };
     auto prepare = [&](int j) OCS_INLINE {   // block j has landed
       // the node before the block's first step, for the objective waves (its slot is recycled before they run)
-      if (lane < TPW) ufirst[j % 3][lane] = j > 0 ? inp[(j - 1) % NSLOT][C_::REC_DBL + (2 * D - 1) * TPW + lane] : a.u[bw + lane];
+      if (lane < TPW) ufirst[j % 4][lane] = j > 0 ? inp[(j - 1) % NSLOT][C_::REC_DBL + (2 * D - 1) * TPW + lane] : a.u[bw + lane];
     };
     P2_BEGIN();
+    // Before barrier k the blocks k and k+1 have landed: P prepares block k+1 during interval k.
     for (int j = 0; j <= Q && j < nb; ++j) issue(j);
     {
-      const int behind = (nb - 1) < Q ? (nb - 1) : Q;
-      wait_blocks_p2<C_::LPB, Q>(behind);
+      const int last = (nb - 1) < Q ? (nb - 1) : Q;   // youngest block issued
+      wait_blocks_p2<C_::LPB, Q>(last - (nb > 1 ? 1 : 0));
       prepare(0);
+      if (nb > 1) prepare(1);
     }
-    for (int k = 0; k <= nb + 1; ++k) {
+    for (int k = -1; k <= nb + 1; ++k) {   // interval -1: P prepares block 0
       P2_BARRIER();
-      // interval k: issue block k+1+Q (its slot last held block k-2, read by C in interval k-1), prepare block k+1
+      if (k < 0) continue;
+      // interval k: issue block k+1+Q (its slot last held block k-2, read by C in interval k-1), wait for block k+2
       if (k + 1 + Q < nb) issue(k + 1 + Q);
-      if (k + 1 < nb) {
-        const int young = nb - 2 - k;   // blocks issued after block k+1
-        wait_blocks_p2<C_::LPB, Q>(young < Q ? young : Q);
-        prepare(k + 1);
+      if (k + 2 < nb) {
+        const int youngest = (k + 1 + Q) < (nb - 1) ? (k + 1 + Q) : (nb - 1);
+        wait_blocks_p2<C_::LPB, Q>(youngest - (k + 2));
+        prepare(k + 2);
       }
     }
     P2_END(0);
@@ -184,17 +188,16 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1], h6U = R0[2];   // step 0's; all steps' on a uniform grid
     P2_BEGIN();
-    for (int k = 0; k <= nb + 1; ++k) {
+    for (int k = -1; k <= nb + 1; ++k) {
       P2_BARRIER();
-      if (k < nb) {
+      if (k >= 0 && k < nb) {
         const double* rec = &inp[k % NSLOT][0];
-        const double* us = rec + C_::REC_DBL + tl;
+        const double2* pw = &prep[k & 1][0][lane];
         double* zw = &zb[k & 1][0][lane];
-        struct In { double uM, uB, h, hh, h6; };
+        struct In { double2 c; double h, hh, h6; };
         auto fetch = [&](int s) OCS_INLINE {
           In v;
-          v.uM = us[(2 * s) * TPW];
-          v.uB = us[(2 * s + 1) * TPW];
+          v.c = pw[s * 64];
           if (!UNI) {
             v.h = rec[RS * s];
             v.hh = rec[RS * s + 1];
@@ -210,8 +213,7 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
           const In c = nxt;
           if (s + 1 < D) nxt = fetch(s + 1);   // the LDS reads of the next step under this step's arithmetic
           __builtin_amdgcn_sched_barrier(0);
-          // (the two control terms are off the dependent chain: they fill its latency bubbles)
-          const double cM = P::row_vertex(mh, c.uM), cB = P::row_vertex(mh, c.uB);
+          const double cM = c.c.x, cB = c.c.y;   // prepared by wave P: every instruction here costs the pass ~9 cycles per step
           zw[s * 64] = z;
           const double F1 = P::row_f_shifted(z, cprev);
           double Z = __builtin_fma(c.hh, F1, z);
@@ -246,14 +248,14 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1];
     P2_BEGIN();
-    for (int k = 0; k <= nb + 1; ++k) {
+    for (int k = -1; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k >= 1 && k <= nb) {
         const int j = k - 1;
         const double* rec = &inp[j % NSLOT][0];
         const double* us = rec + C_::REC_DBL + ctl;
         const double* zr = &zb[j & 1][0][0];
-        const double ublk = ufirst[j % 3][ctl];
+        const double ublk = ufirst[j % 4][ctl];
         const BufP2 bx = BufP2::make(a.x + (size_t)(j * D) * colB);
 #pragma unroll
         for (int p = 0; p < C_::NPASS; ++p) {
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
       }
     }
     P2_END(wave);
-  } else {
+  } else if (wave == 2 + NCW) {
     // ---------------- J: running objective ----------------
     // lane (sg, tl): SPJ = D / G consecutive steps of trajectory tl, starting at step sg SPJ; the sum over the lanes
     // of a trajectory through the LDS crossbar
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     double carry = 0.0;   // running objective at the first node of the block
     if (wc && !fz && sg == 0) a.x[(size_t)G * B + b] = 0.0;
     P2_BEGIN();
-    for (int k = 0; k <= nb + 1; ++k) {
+    for (int k = -1; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k >= 2) {   // k <= nb + 1: block j <= nb - 1
         const int j = k - 2;
@@ -340,6 +342,31 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     }
     P2_END(wave);
     if (!fz && sg == 0) a.J[b] = carry;
+  } else {
+    // ---------------- P: the control terms of the next block for S ----------------
+    // P::row_vertex(m_r/2, u) = m_r^2/4 - u for the two new samples of every step, per S lane: two instructions less
+    // on the recursion wave, which is bound by its instruction count
+    const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
+    const typename P::RowPar rp = P::load_row([&](int k) OCS_INLINE {
+      return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];
+    }, r);
+    const double mh = P::row_shift(rp);
+    auto prepare = [&](int j) OCS_INLINE {   // block j has landed (M waits one block ahead of the barrier)
+      const double* us = &inp[j % NSLOT][C_::REC_DBL] + tl;
+      double2* w = &prep[j & 1][0][lane];
+#pragma unroll
+      for (int s = 0; s < D; ++s)
+        w[s * 64] = double2{P::row_vertex(mh, us[(2 * s) * TPW]), P::row_vertex(mh, us[(2 * s + 1) * TPW])};
+    };
+    // block 0 before the first barrier: M's own wait for it is not visible here, so P waits for the data itself --
+    // the first barrier below is only passed by M after blocks 0 and 1 have landed; prepare(0) therefore runs in
+    // "interval -1": one extra barrier at the head of every wave's loop
+    P2_BEGIN();
+    for (int k = -1; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      if (k + 1 < nb) prepare(k + 1);   // read by S in interval k+1; prep[(k+1)&1] was last read in interval k-1
+    }
+    P2_END(wave);
   }
 }
 

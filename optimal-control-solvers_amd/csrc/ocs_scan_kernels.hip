@@ -44,21 +44,39 @@ static inline int hip_rc6(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 // addresser works through a wave's addresses a quad at a time, and with the row index fastest (lane = tl G + r,
 // the layout of the row-split / pipeline kernels) every quad spans G lines -- measured 3.5 TB/s against 6 TB/s
 // for the same bytes.  The price: sums over the rows of a trajectory cross lanes 16 or 32 apart, which DPP
-// cannot reach; they go through the LDS crossbar (ds_bpermute, no LDS memory involved).
+// cannot reach; they use the row-swapping permlane instructions of gfx950 (swap_add16 / swap_add32 below).
+// v_permlane16_swap(vdst, src): the odd 16-lane rows of vdst trade places with the even rows of src;
+// v_permlane32_swap: the upper half of vdst with the lower half of src.  With (a, b) in, the two results added give
+// per row [a0+a1, b0+b1, a2+a3, b2+b3] -- a transposing pair reduction in two instructions per 32-bit half, in the
+// vector pipe (ds_bpermute, the alternative, parks the wave for an LDS round trip: 13 % of its cycles were measured).
+__device__ static inline double swap_add16(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+__device__ static inline double swap_add32(double a, double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  return __hiloint2double((int)hi[0], (int)lo[0]) + __hiloint2double((int)hi[1], (int)lo[1]);
+}
+// sum over the G rows of a trajectory (lanes r TPW + tl), in every lane
 template <int G>
-__device__ static inline double group_sum_sc(double v, int xaddr16, int xaddr32) {
+__device__ static inline double group_sum_sc(double v) {
   static_assert(G == 1 || G == 2 || G == 4, "group size");
-  if (G == 4) {   // rows at lane bits 4 and 5
-    const int lo = __builtin_amdgcn_ds_bpermute(xaddr16, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(xaddr16, __double2hiint(v));
-    v += __hiloint2double(hi, lo);
-  }
-  if (G >= 2) {   // rows (G = 2) or row pairs (G = 4) at lane bit 5
-    const int lo = __builtin_amdgcn_ds_bpermute(xaddr32, __double2loint(v));
-    const int hi = __builtin_amdgcn_ds_bpermute(xaddr32, __double2hiint(v));
-    v += __hiloint2double(hi, lo);
-  }
+  if (G == 4) v = swap_add16(v, v);
+  if (G >= 2) v = swap_add32(v, v);
   return v;
+}
+// two sums at once: lanes of even row r get sum_r a, lanes of odd row r get sum_r b
+template <int G>
+__device__ static inline double pair_sum_sc(double a, double b) {
+  static_assert(G == 1 || G == 2 || G == 4, "group size");
+  if (G == 1) return a;   // (not used: one lane per trajectory has nothing to sum)
+  if (G == 4) {
+    const double s = swap_add16(a, b);   // rows: [a0+a1, b0+b1, a2+a3, b2+b3]
+    return swap_add32(s, s);             //       [sum a, sum b, sum a, sum b]
+  }
+  return swap_add32(a, b);               // halves (= rows): [a0+a1, b0+b1]
 }
 __device__ static inline void lds_barrier_sc() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
@@ -141,11 +159,11 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
   static_assert(P::NC == 1 && P::NTC == 1 && P::ROW_SEPARABLE, "scan kernels: row-separable problems, one control");
   static_assert(L % G == 0 && W * L + 1 <= kScanPadFront && L + 1 <= 16, "chunk shape");
   __shared__ __attribute__((aligned(16))) double2 sm[2][W][64];      // chunk maps
+  __shared__ double csm[2][64];                                      // lam at the bottom of a superblock
   __shared__ __attribute__((aligned(16))) double rcs[2][W][16 * kScanRec];  // records lo-1 .. lo+14 of a wave's chunk
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const int r = lane / TPW, tl = lane % TPW;   // trajectory fastest (see group_sum_sc)
-  const int xa16 = (lane ^ 16) * 4, xa32 = (lane ^ 32) * 4;
   const size_t B = (size_t)a.batch;
   const int N = a.N;
   const int b0 = blockIdx.x * TPW + tl;
@@ -204,7 +222,6 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
 #pragma unroll
     for (int q = 0; q < L; ++q) load_part(sb, d, slot, q);
   };
-  constexpr int NLD = 3 * L + 2;                               // vector-memory operations of load()
   constexpr int NST = (OUT_LAM ? L + L / G : 0) + (OUT_DJDU ? (G == 1 ? 2 * L + 1 : (G == 2 ? L + 1 : L)) : 0);
   struct Rc { double h, hh, h6, h3, e4, e3, e1; };
   auto rec_of = [&](const double* w, int q) OCS_INLINE {   // record of step lo + q (q = -1: the step below the chunk)
@@ -260,22 +277,27 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
     }
     sm[sb & 1][wave][lane] = double2{A, Bq};
     if (ABL != 5) lds_barrier_sc();
-    // ---------------- phase 2: lam at the top of this chunk, and the next carry ----------------
-    double lam = carry, top = carry;
+    // ---------------- phase 2: lam at the top of this chunk ----------------
+    // lam at the top of the superblock: lamT for the first one, afterwards what the LAST wave of the previous
+    // superblock left at the bottom of its chunk (published to LDS behind its phase 3, i.e. before this superblock's
+    // barrier) -- so every wave composes only the maps of the chunks above its own, in groups of four (all W at once
+    // would hold 4 W registers), and superblock boundaries carry the serial recursion's own value.
+    double lam = (sb == 0) ? carry : csm[(sb & 1) ^ 1][lane];
 #pragma unroll
-    for (int j0 = 0; j0 < W && ABL != 5; j0 += 4) {   // four maps in flight (all W at once would hold 4 W registers)
-      double2 ab[4];
+    for (int j0 = 0; j0 < W && ABL != 5; j0 += 4) {
+      if (j0 < wave) {   // wave-uniform
+        double2 ab[4];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) ab[j] = sm[sb & 1][j0 + j][lane];
+        for (int j = 0; j < 4; ++j) ab[j] = sm[sb & 1][j0 + j][lane];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        top = (j0 + j == wave) ? lam : top;
-        lam = __builtin_fma(ab[j].x, lam, ab[j].y);
+        for (int j = 0; j < 4; ++j) {
+          if (j0 + j < wave) {   // wave-uniform; the fence keeps it a branch (two selects per map otherwise)
+            lam = __builtin_fma(ab[j].x, lam, ab[j].y);
+            asm volatile("" : "+v"(lam));
+          }
+        }
       }
-      __builtin_amdgcn_sched_barrier(0);
     }
-    carry = lam;
-    lam = top;
     // ---------------- phase 3: the recursion inside the chunk, lam and dJdu stores ----------------
     const int lc = live ? lo : 0, nrec = (live && ABL != 1) ? kNumRec : 0;   // a dead chunk stores nothing
     const Buf bl = Buf::make(a.lam + (size_t)lc * colB, nrec), bd = Buf::make(a.dJdu + (size_t)(2 * lc) * B, nrec);
@@ -285,7 +307,7 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
       for (int q0 = 0; q0 < L; q0 += G) bl.st(lamc, vc, (unsigned)q0 * col8);
     }
     double pend = topc ? pend_top : 0.0;   // this row's B'k1 share of the node above
-    if (ABL == 2) carry += d.x[0] + d.u[0];
+    if (ABL == 2) lam += d.x[0] + d.u[0];
 #pragma unroll
     for (int q = L - 1; q >= 0 && ABL != 2; --q) {
       const Rc c = rec_of(rw, q);
@@ -313,8 +335,15 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
         const double cuA = rp.cw * d.u[2 * q], cuM = rp.cw * d.u[2 * q + 1], cuB = rp.cw * d.u[2 * q + 2];
         const double p4 = P::row_dfdu(cuB, k4, ev4);
         const double p23 = P::row_dfdu(cuM, k3, ev3) + P::row_dfdu(cuM, k2, ev3);
-        const double cnode = group_sum_sc<G>(pend + p4, xa16, xa32);         // column 2i+2 (it belongs to the chunk of step i+1,
-        const double cmid = group_sum_sc<G>(p23, xa16, xa32);                //  except column 2N); column 2i+1
+        // column 2i+1 (sum of p23 over the rows) and column 2i+2 (sum of pend + p4; it belongs to the chunk of step
+        // i+1, except column 2N): lanes of row 0 end up with the first, lanes of row 1 with the second
+        double cmid, cnode;
+        if (G == 1) {
+          cmid = p23;
+          cnode = pend + p4;
+        } else {
+          cmid = cnode = pair_sum_sc<G>(p23, pend + p4);
+        }
         pend = P::row_dfdu(cuA, k1, ev1);
         const unsigned so = (unsigned)(2 * q) * B8;
         double cbot = 0.0;
@@ -323,7 +352,7 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
           // dFdu_times_vec of these problems does not read y); column 0 has the k1 half only  :101-102
           const Rc cb = rec_of(rw, -1);
           const double ev4b = LT ? cb.e4 * lamc : cb.e4;
-          cbot = group_sum_sc<G>(pend + P::row_dfdu(cuA, cb.h6 * lam, ev4b), xa16, xa32);
+          cbot = group_sum_sc<G>(pend + P::row_dfdu(cuA, cb.h6 * lam, ev4b));
         }
         if (G == 1) {
           bd.st(cmid, vd_mid, so);
@@ -345,6 +374,8 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (wave == W - 1) csm[sb & 1][lane] = lam;   // lam at the bottom of the superblock (a dead chunk passes it through)
+    carry = lam;
   };
 
   // Superblocks in pairs (two register sets, no register moves); a superblock past the horizon loads clamped
@@ -356,7 +387,7 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
     process(sb, d0, 0, sb == 0, d1);
     process(sb + 1, d1, 1, false, d0);
   }
-  if (a.lam0 && wave == 0 && valid) {
+  if (a.lam0 && wave == W - 1 && valid) {   // the last wave's chunk ends at (or, dead, passes through) step 0
     a.lam0[(size_t)r * B + b] = carry;
     if (r == 0) a.lam0[(size_t)G * B + b] = lamc;
   }
