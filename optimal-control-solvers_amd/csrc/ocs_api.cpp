@@ -118,6 +118,9 @@ int ocs_problem_set_batch_params(ocs_problem p, int batch, const int* param_inde
   OCS_TRY(upload_problem(p));
   const int npar = (int)p->par.size();
   if (npar > 32) return fail(OCS_ERR_UNSUPPORTED, "per-trajectory parameters need <= 32 parameters");
+  if (p->user && (npar > 16 || user_rowsep(p->user)))
+    return fail(OCS_ERR_UNSUPPORTED, "user problems with more than 16 parameters or given as row functions read the "
+                                     "shared parameter block only: no per-trajectory parameters");
   const unsigned tcmask = functor_tc_param_mask(p->functor, p->nS);
   unsigned mask = 0;
   std::vector<double> pb((size_t)npar * batch, 0.0);

@@ -4,6 +4,9 @@
 #pragma once
 #include "ocs_device_common.hpp"
 
+#ifndef OCS_FBS_USTORE
+#define OCS_FBS_USTORE(v, p) (*(p) = (v))
+#endif
 namespace ocs {
 
 // ---------------------------------------------------------------------------------------
@@ -414,7 +417,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
           any = true;
         }
       }
-      *dst = u[c];
+      OCS_FBS_USTORE(u[c], dst);
     }
   };
 #pragma unroll

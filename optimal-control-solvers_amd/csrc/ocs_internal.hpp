@@ -41,6 +41,10 @@ int launch_tcoef(const ProblemDesc& p, const GridDesc& g, hipStream_t s);
 enum Mapping : int { MAP_AUTO = 0, MAP_LANE = 1, MAP_ROWSPLIT = 2, MAP_PIPELINE = 3, MAP_SCAN = 4 };
 // adjoint pass as a scan over time (ocs_scan_kernels.hip): row-separable problems, any N, any batch
 bool scan_supported(Functor f, int nS, int nC);
+// the same for a bound problem: registry problems as above, user problems if given as row functions (hipRTC instances)
+bool user_rowsep(const UserModule* m);
+bool scan_problem_ok(const ProblemDesc& p);
+bool pipeline_problem_ok(const ProblemDesc& p);
 // N a multiple of scan_chunk_steps(); pend0 as for launch_backward_pl
 int scan_chunk_steps();
 int launch_backward_scan(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,

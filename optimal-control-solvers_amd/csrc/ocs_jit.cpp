@@ -62,7 +62,7 @@ static Rtc* rtc() {
 
 int user_chunk(int nS) { return nS <= 4 ? 4 : 1; }
 
-static std::vector<std::string> kernel_names(int nS) {
+static std::vector<std::string> kernel_names(int nS, bool rowsep) {
   const std::string ch = std::to_string(user_chunk(nS));
   std::vector<std::string> n(UK_COUNT);
   n[UK_TCOEF] = "ocs::k_tcoef<ocs::UserP>";
@@ -80,12 +80,22 @@ static std::vector<std::string> kernel_names(int nS) {
   n[UK_CONTROL_PTS] = "ocs::k_control_pts<ocs::UserP>";
   n[UK_TU_AT] = "ocs::k_tu_at<ocs::UserP>";
   n[UK_EQUILIBRIUM] = "ocs::k_equilibrium<ocs::UserP>";
+  if (rowsep) {   // (entries left empty are not compiled)
+    n[UK_FWD_P2_X] = "ocs::k_forward_p2<ocs::UserP, true, true, false>";
+    n[UK_FWD_P2_J] = "ocs::k_forward_p2<ocs::UserP, false, true, false>";
+    n[UK_SCAN_LAM_DJDU] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, true, false, 0>";
+    n[UK_SCAN_LAM] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, false, false, 0>";
+    n[UK_SCAN_DJDU] = "ocs::k_backward_scan<ocs::UserP, 16, 4, false, true, false, 0>";
+    n[UK_SCAN_LAM_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, true, true, 0>";
+    n[UK_SCAN_LAM_LT] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, false, true, 0>";
+    n[UK_SCAN_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, 16, 4, false, true, true, 0>";
+  }
   return n;
 }
 
 // Compiles the user's source.  `load` = false stops after compilation (usable without a GPU).
 int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool load, UserModule** out,
-              std::string& log) {
+              std::string& log, bool rowsep) {
   Rtc* r = rtc();
   if (!r) {
     log = "hipRTC (libhiprtc.so) could not be loaded";
@@ -96,24 +106,27 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   src += "#define OCS_USER_NS " + std::to_string(nS) + "\n#define OCS_USER_NC " + std::to_string(nC) +
          "\n#define OCS_USER_NPAR " + std::to_string(npar) + "\n";
   if (has_cc) src += "#define OCS_USER_HAS_CONTROLCHAR 1\n";
+  if (rowsep) src += "#define OCS_USER_ROWSEP 1\n";
   src += "#include \"ocs_device_common.hpp\"\n";
   src += "constexpr int NS = OCS_USER_NS, NC = OCS_USER_NC, NPAR = OCS_USER_NPAR;\n";
-  src += npar <= 16 ? "typedef const double* OCS_PARAMS;\n" : "typedef ocs::uniform_ptr OCS_PARAMS;\n";
+  src += (npar <= 16 && !rowsep) ? "typedef const double* OCS_PARAMS;\n" : "typedef ocs::uniform_ptr OCS_PARAMS;\n";
   src += "#line 1 \"user_problem\"\n";
   src += user_src;
   src += "\n#include \"ocs_user_functor.hpp\"\n#include \"ocs_rk4_kernels.hpp\"\n#include \"ocs_fbs_device.hpp\"\n";
+  if (rowsep) src += "#include \"ocs_pipeline2_kernel.hpp\"\n#include \"ocs_scan_kernel.hpp\"\n";
 
   const char* hdr_src[] = {src_ocs_device_common_hpp, src_ocs_user_functor_hpp, src_ocs_rk4_kernels_hpp,
-                           src_ocs_fbs_device_hpp};
+                           src_ocs_fbs_device_hpp, src_ocs_pipeline2_kernel_hpp, src_ocs_scan_kernel_hpp};
   const char* hdr_name[] = {"ocs_device_common.hpp", "ocs_user_functor.hpp", "ocs_rk4_kernels.hpp",
-                            "ocs_fbs_device.hpp"};
+                            "ocs_fbs_device.hpp", "ocs_pipeline2_kernel.hpp", "ocs_scan_kernel.hpp"};
   hiprtcProgram prog = nullptr;
-  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 4, hdr_src, hdr_name) != 0) {
+  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 6, hdr_src, hdr_name) != 0) {
     log = "hiprtcCreateProgram failed";
     return OCS_ERR_HIP;
   }
-  const std::vector<std::string> names = kernel_names(nS);
-  for (const std::string& n : names) r->AddNameExpression(prog, n.c_str());
+  const std::vector<std::string> names = kernel_names(nS, rowsep);
+  for (const std::string& n : names)
+    if (!n.empty()) r->AddNameExpression(prog, n.c_str());
   const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
   const hiprtcResult rc = r->CompileProgram(prog, 4, opts);
   size_t logsz = 0;
@@ -132,9 +145,11 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   m->nC = nC;
   m->npar = npar;
   m->has_cc = has_cc;
+  m->rowsep = rowsep;
   m->chunk = user_chunk(nS);
   std::vector<std::string> lowered(UK_COUNT);
   for (int k = 0; k < UK_COUNT; ++k) {
+    if (names[k].empty()) continue;
     const char* ln = nullptr;
     if (r->GetLoweredName(prog, names[k].c_str(), &ln) != 0 || !ln) {
       r->DestroyProgram(&prog);
@@ -161,7 +176,7 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
       return OCS_ERR_HIP;
     }
     for (int k = 0; k < UK_COUNT; ++k)
-      if (hipModuleGetFunction(&m->fn[k], m->mod, lowered[k].c_str()) != hipSuccess) {
+      if (!names[k].empty() && hipModuleGetFunction(&m->fn[k], m->mod, lowered[k].c_str()) != hipSuccess) {
         log = "kernel " + names[k] + " missing from the compiled module";
         (void)hipModuleUnload(m->mod);
         delete m;
@@ -173,15 +188,17 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   return OCS_OK;
 }
 
+bool user_rowsep(const UserModule* m) { return m && m->rowsep; }
+
 void jit_free(UserModule* m) {
   if (!m) return;
   if (m->loaded) (void)hipModuleUnload(m->mod);
   delete m;
 }
 
-int jit_launch(const UserModule* m, int kid, dim3 grid, dim3 block, void** params, hipStream_t s) {
-  if (!m || !m->loaded) return -1;
-  const hipError_t e = hipModuleLaunchKernel(m->fn[kid], grid.x, grid.y, grid.z, block.x, block.y, block.z, 0, s,
+int jit_launch(const UserModule* m, int kid, dim3 grid, dim3 block, void** params, hipStream_t s, unsigned shmem) {
+  if (!m || !m->loaded || !m->fn[kid]) return -1;
+  const hipError_t e = hipModuleLaunchKernel(m->fn[kid], grid.x, grid.y, grid.z, block.x, block.y, block.z, shmem, s,
                                              params, nullptr);
   return e == hipSuccess ? 0 : (int)e;
 }
@@ -201,7 +218,10 @@ int ocs_problem_create_from_source(ocs_problem* out, const char* source, int nS,
   if (nS < 1 || nS > 64 || nC < 1 || nC > 8 || nparams < 0) return fail(OCS_ERR_SHAPE, "need 1 <= nS <= 64, 1 <= nC <= 8");
   std::string log;
   UserModule* m = nullptr;
-  const int rc = jit_build(source, nS, nC, nparams, has_control_char != 0, true, &m, log);
+  const bool rowsep = (has_control_char & 2) != 0;   // flag word: bit 0 ocs_ControlChar present, bit 1 row functions
+  if (rowsep && (nC != 1 || nparams > 16 || !(nS == 1 || nS == 2 || nS == 4)))
+    return fail(OCS_ERR_SHAPE, "a problem given as row functions needs nC = 1, nS in {1, 2, 4} and at most 16 parameters");
+  const int rc = jit_build(source, nS, nC, nparams, (has_control_char & 1) != 0, true, &m, log, rowsep);
   if (rc != OCS_OK) return fail(rc, "user problem: %s", log.substr(0, 400).c_str());
   ocs_problem_s* p = new ocs_problem_s();
   p->id = OCS_PROBLEM_USER;
@@ -225,7 +245,7 @@ int ocs_problem_check_source(const char* source, int nS, int nC, int nparams, in
   if (!source) return fail(OCS_ERR_INVALID, "null argument");
   std::string log;
   UserModule* m = nullptr;
-  const int rc = jit_build(source, nS, nC, nparams, has_control_char != 0, false, &m, log);
+  const int rc = jit_build(source, nS, nC, nparams, (has_control_char & 1) != 0, false, &m, log, (has_control_char & 2) != 0);
   if (rc != OCS_OK) return fail(rc, "user problem: %s", log.substr(0, 400).c_str());
   jit_free(m);
   return OCS_OK;

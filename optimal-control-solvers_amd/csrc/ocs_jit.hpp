@@ -9,20 +9,23 @@ namespace ocs {
 
 enum UserKernel : int {
   UK_TCOEF = 0, UK_BUILD_REC, UK_FWD_X, UK_FWD_J, UK_FWD_UCONST, UK_BWD_LAM_DJDU, UK_BWD_LAM, UK_BWD_DJDU,
-  UK_BWD_UCONST, UK_EVAL, UK_COSTATE, UK_CONTROL_GRID, UK_CONTROL_PTS, UK_TU_AT, UK_EQUILIBRIUM, UK_COUNT
+  UK_BWD_UCONST, UK_EVAL, UK_COSTATE, UK_CONTROL_GRID, UK_CONTROL_PTS, UK_TU_AT, UK_EQUILIBRIUM,
+  // row-separable user problems only (OCS_USER_ROWSEP): the wave-specialised state pass and the scan adjoint pass
+  UK_FWD_P2_X, UK_FWD_P2_J, UK_SCAN_LAM_DJDU, UK_SCAN_LAM, UK_SCAN_DJDU, UK_SCAN_LAM_DJDU_LT, UK_SCAN_LAM_LT, UK_SCAN_DJDU_LT,
+  UK_COUNT
 };
 
 struct UserModule {
   int nS = 0, nC = 0, npar = 0, chunk = 4;
-  bool has_cc = false, loaded = false;
+  bool has_cc = false, loaded = false, rowsep = false;
   std::vector<char> code;
   hipModule_t mod = nullptr;
   hipFunction_t fn[UK_COUNT] = {};
 };
 
 int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool load, UserModule** out,
-              std::string& log);
+              std::string& log, bool rowsep = false);
 void jit_free(UserModule* m);
-int jit_launch(const UserModule* m, int kid, dim3 grid, dim3 block, void** params, hipStream_t s);
+int jit_launch(const UserModule* m, int kid, dim3 grid, dim3 block, void** params, hipStream_t s, unsigned shmem = 0);
 
 }  // namespace ocs

@@ -157,7 +157,9 @@ static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
 // the one-kernel result bit for bit.  splits(): 0 = no pipeline, else the number of pipeline steps.
 static int pipeline_steps(const ProblemDesc& p, int N, int batch, bool backward) {
   const int D = pipeline_block_steps(), N1 = (N / D) * D;
-  if (!pipeline_supported(p.functor, p.nS, p.nC) || N1 < D || !pipeline_shape_ok(p.nS, N1, batch, backward)) return 0;
+  // (user problems given as row functions have the state-pass kernel only: their adjoint pass is the scan)
+  if (backward ? !pipeline_supported(p.functor, p.nS, p.nC) : !pipeline_problem_ok(p)) return 0;
+  if (N1 < D || !pipeline_shape_ok(p.nS, N1, batch, backward)) return 0;
   return N1;
 }
 // boundary: the caller's output arrays can carry the hand-over column of a split pass (x forward, lam backward)
@@ -206,6 +208,10 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
     const FwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
                     p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, o.frozen, o.dump, xb + (size_t)p.nS * ldb,
                     o.ld};
+    if (p.functor == Functor::User) {
+      void* args[] = {(void*)&a};
+      return jit_launch(p.user, UK_FWD_X, dim3((batch + 63) / 64), dim3(64), args, s);
+    }
     OCS_DISPATCH_LOGISTIC(p.nS, run_forward<P>(a, false, s));
     return hip_rc(hipGetLastError());
   }
@@ -247,7 +253,7 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
   // first on the lane kernel (which hands lam(:, N1) and the k1 half of column 2 N1 over through the output arrays),
   // so a split pass needs the lam array.
   const int Ls = scan_chunk_steps(), Ns = (g.N / Ls) * Ls;
-  const bool scan_ok = plain && g.RECS && scan_supported(p.functor, p.nS, p.nC) && Ns >= Ls && (Ns == g.N || lam || o.split_scratch);
+  const bool scan_ok = plain && g.RECS && scan_problem_ok(p) && Ns >= Ls && (Ns == g.N || lam || o.split_scratch);
   if (o.mapping == MAP_AUTO && scan_ok && scan_pays(p.nS, g.N, batch)) map = MAP_SCAN;
   if (map == MAP_SCAN) {
     if (!scan_ok) return -1;
@@ -258,8 +264,15 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
     const BwdArgs a{g.N - Ns, batch, g.REC + (size_t)Ns * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
                     p.pmask, xck + (size_t)Ns * col, u + (size_t)(2 * Ns) * ucol, lamT, lam ? lamb : nullptr, db,
                     lam ? nullptr : lamb};
-    OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, false, s));
-    int rc = hip_rc(hipGetLastError());
+    int rc;
+    if (p.functor == Functor::User) {
+      void* args[] = {(void*)&a};
+      rc = jit_launch(p.user, a.lam && a.dJdu ? UK_BWD_LAM_DJDU : (a.lam ? UK_BWD_LAM : UK_BWD_DJDU),
+                      dim3((batch + 63) / 64), dim3(64), args, s);
+    } else {
+      OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, false, s));
+      rc = hip_rc(hipGetLastError());
+    }
     if (rc) return rc;
     GridDesc g1 = g;
     g1.N = Ns;

@@ -149,6 +149,34 @@ struct LogisticK {
     return __builtin_fma(cu, ev, -v);
   }
 
+  // ---- generic row-separable interface (the names the scan / pipeline kernels call; a user problem given as row
+  //      functions implements the same names in ocs_user_functor.hpp) ------------------------------------------------
+  // Stage: what a stage evaluation of the adjoint needs besides y, u: built from the step record (sc = the problem's
+  // step constant of that stage, w = h/6 or h/3, tc = the time coefficient of the stage's grid point) and lam(end).
+  static constexpr bool DFDU_READS_Y = false;   // (dF/du)'v of these rows does not depend on y
+  static constexpr bool HAS_SHIFT = true;       // the state recursion may run on z = y - row_shift (row_f_shifted)
+  struct Stage { double ev; };
+  template <bool LT>
+  __device__ static inline Stage stage(double sc, double w, double tc, double lamc) {
+    (void)w; (void)tc;
+    return Stage{LT ? sc * lamc : sc};
+  }
+  __device__ static inline double g_row_f(double y, double u, double tc, const RowPar& rp) { (void)tc; return row_f(y, u, rp); }
+  // this row's share of the objective integrand at a stage (time coefficient included)
+  __device__ static inline double g_row_q(double y, double u, double tc, const RowPar& rp) { return tc * row_q(y, u * u, rp); }
+  __device__ static inline void g_row_dfdx_pre(double y, double u, const Stage& st, const RowPar& rp, double& a, double& b) {
+    (void)u;
+    row_dfdx_pre(y, st.ev, rp, a, b);
+  }
+  __device__ static inline double g_row_dfdx(double y, double u, double v, const Stage& st, const RowPar& rp) {
+    (void)u;
+    return row_dfdx(y, v, st.ev, rp);
+  }
+  __device__ static inline double g_row_dfdu(double y, double u, double v, const Stage& st, const RowPar& rp) {
+    (void)y;
+    return row_dfdu(rp.cw * u, v, st.ev);
+  }
+
   // Gen-1 ControlChar through the A9 adapter (make_from_symbolic.m:19-23,111):
   //   dHdu = -sum(lam) + 2 c e^{-rt} u = 0  ->  u = sum(lam) e^{rt} / (2c), clamped to the bounds.
   __device__ static inline void control_char(const double* tu, const double* x, const double* lam,

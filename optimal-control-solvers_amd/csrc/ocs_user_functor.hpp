@@ -16,8 +16,54 @@
 //
 // NS, NC, NPAR are available as constants.  OCS_PARAMS is `const double*` (a per-trajectory register copy,
 // so per-trajectory parameter overrides work) when NPAR <= 16, and a pointer to the shared parameter block
-// in constant address space (scalar loads) otherwise.
+// in constant address space (scalar loads) otherwise, and always for problems given as row functions.
 #pragma once
+
+// ---- row-separable user problems (OCS_USER_ROWSEP) --------------------------------------------------------------
+// A problem whose state rows are uncoupled -- row r of F reads y_r, u and t only, and the objective integrand is a sum
+// of per-row shares -- may be given as ROW FUNCTIONS instead of the three full-vector methods:
+//   __device__ double ocs_row_tcoef(double t, OCS_PARAMS p);                              time coefficient tc(t)
+//   __device__ double ocs_row_F(double tc, double y, double u, OCS_PARAMS p, int r);      F_r(t, y_r, u)
+//   __device__ double ocs_row_q(double tc, double y, double u, OCS_PARAMS p, int r);      share of F(end): sum_r = integrand
+//   __device__ void   ocs_row_dFdy(double tc, double y, double u, OCS_PARAMS p, int r, double* dF, double* dq);
+//                                                                  dF_r/dy_r and dq_r/dy_r
+//   __device__ void   ocs_row_dFdu(double tc, double y, double u, OCS_PARAMS p, int r, double* dF, double* dq);
+//                                                                  dF_r/du and dq_r/du
+// Time enters the row functions through ONE coefficient tc = ocs_row_tcoef(t, p), evaluated once per grid point into
+// the step records (return t itself if the rows need the time; return e.g. exp(-r t) for a discounted objective, which
+// keeps the transcendental off the per-stage path as tests/TestOCProblem.m:25,31,37 are hoisted for the registry
+// problems); the parameters it reads must be the same for all trajectories.  ocs_ControlChar still receives t.
+// (NC = 1.)  The full-vector plugin methods of OCProblem.m:8-21 are derived from them below, so every kernel works; in
+// addition the wave-specialised state pass and the scan adjoint pass (the mappings of the registry problems) are
+// instantiated for the problem.
+#ifdef OCS_USER_ROWSEP
+__device__ static inline void ocs_F(double t, const double* y, const double* u, OCS_PARAMS p, double* f) {
+  double s = 0.0;
+  for (int k = 0; k < OCS_USER_NS; ++k) {
+    f[k] = ocs_row_F(t, y[k], u[0], p, k);
+    s += ocs_row_q(t, y[k], u[0], p, k);
+  }
+  f[OCS_USER_NS] = s;
+}
+__device__ static inline void ocs_dFdx_times_vec(double t, const double* y, const double* u, OCS_PARAMS p,
+                                                 const double* v, double* g) {
+  for (int k = 0; k < OCS_USER_NS; ++k) {
+    double dF, dq;
+    ocs_row_dFdy(t, y[k], u[0], p, k, &dF, &dq);
+    g[k] = __builtin_fma(dF, v[k], dq * v[OCS_USER_NS]);
+  }
+}
+__device__ static inline void ocs_dFdu_times_vec(double t, const double* y, const double* u, OCS_PARAMS p,
+                                                 const double* v, double* g) {
+  double s = 0.0;
+  for (int k = 0; k < OCS_USER_NS; ++k) {
+    double dF, dq;
+    ocs_row_dFdu(t, y[k], u[0], p, k, &dF, &dq);
+    s += __builtin_fma(dF, v[k], dq * v[OCS_USER_NS]);
+  }
+  g[0] = s;
+}
+#endif
 
 namespace ocs {
 
@@ -31,7 +77,7 @@ struct UserP {
   static constexpr int NSC = 0;
   static constexpr unsigned TC_PARAM_MASK = 0u;
 
-#if OCS_USER_NPAR <= 16
+#if OCS_USER_NPAR <= 16 && !defined(OCS_USER_ROWSEP)
   struct Par {
     double p[OCS_USER_NPAR > 0 ? OCS_USER_NPAR : 1];
   };
@@ -50,8 +96,13 @@ struct UserP {
   __device__ static inline uniform_ptr par(const Par& q) { return q.p; }
 #endif
 
-  __device__ static inline void tcoef(double t, const double*, double* tc, double* tu) {
+  __device__ static inline void tcoef(double t, const double* ps, double* tc, double* tu) {
+#ifdef OCS_USER_ROWSEP
+    tc[0] = ocs_row_tcoef(t, (OCS_PARAMS)ps);   // the user's time coefficient (shared parameters)
+#else
+    (void)ps;
     tc[0] = t;
+#endif
     tu[0] = t;
   }
   __device__ static inline void step_consts(double, double, const double*, const double*, const double*, double*) {}
@@ -73,6 +124,55 @@ struct UserP {
                                       const double* v, double* g) {
     ocs_dFdu_times_vec(tc[0], y, u, par(p), v, g);
   }
+#ifdef OCS_USER_ROWSEP
+  // ---- generic row-separable interface (ocs_problems.hpp) over the user's row functions ----
+  static constexpr bool ROW_SEPARABLE = true;
+  static constexpr bool DFDU_READS_Y = true;    // unknown: assume (dF/du)'v may read y
+  static constexpr bool HAS_SHIFT = false;
+  struct RowPar {
+    Par p;
+    int r;
+  };
+  // (row functions index the parameters by the row number, a per-lane value: a register copy of the block would
+  //  live in scratch memory.  They read the shared block in constant address space instead -- invariant loads the
+  //  compiler hoists out of the time loop -- so per-trajectory parameter overrides do not apply to these problems.)
+  __device__ static inline RowPar load_row(const ParamSrc& g, int r) { return RowPar{Par{g.ps}, r}; }
+  struct Stage { double t, kc; };   // time of the stage's grid point, cost-row entry of dJdk (h/6 or h/3 times lam(end))
+  template <bool LT>
+  __device__ static inline Stage stage(double sc, double w, double tc, double lamc) {
+    (void)sc;
+    return Stage{tc, LT ? w * lamc : w};
+  }
+  __device__ static inline double g_row_f(double y, double u, double tc, const RowPar& rp) {
+    return ocs_row_F(tc, y, u, par(rp.p), rp.r);
+  }
+  __device__ static inline double g_row_q(double y, double u, double tc, const RowPar& rp) {
+    return ocs_row_q(tc, y, u, par(rp.p), rp.r);
+  }
+  __device__ static inline void g_row_dfdx_pre(double y, double u, const Stage& st, const RowPar& rp, double& a, double& b) {
+    double dF, dq;
+    ocs_row_dFdy(st.t, y, u, par(rp.p), rp.r, &dF, &dq);
+    a = dF;
+    b = dq * st.kc;
+  }
+  __device__ static inline double g_row_dfdx(double y, double u, double v, const Stage& st, const RowPar& rp) {
+    double dF, dq;
+    ocs_row_dFdy(st.t, y, u, par(rp.p), rp.r, &dF, &dq);
+    return __builtin_fma(dF, v, dq * st.kc);
+  }
+  __device__ static inline double g_row_dfdu(double y, double u, double v, const Stage& st, const RowPar& rp) {
+    double dF, dq;
+    ocs_row_dFdu(st.t, y, u, par(rp.p), rp.r, &dF, &dq);
+    return __builtin_fma(dF, v, dq * st.kc);
+  }
+  // (names of the shifted form of the registry problems: never called, HAS_SHIFT is false)
+  __device__ static inline double row_shift(const RowPar&) { return 0.0; }
+  __device__ static inline double row_vertex(double, double u) { return u; }
+  __device__ static inline double row_f_shifted(double z, double) { return z; }
+  __device__ static inline double control_q(double, const RowPar&) { return 0.0; }
+  __device__ static inline double state_q_acc(double, double acc) { return acc; }
+#endif
+
   __device__ static inline void control_char(const double* tu, const double* x, const double* lam, const Par& p,
                                              const double* lb, const double* ub, double* u) {
 #ifdef OCS_USER_HAS_CONTROLCHAR

@@ -5,7 +5,8 @@ import numpy as np
 import pytest
 
 from oracle import np_twin as tw
-from tests.user_problems import (LOGISTIC2_SRC, PREDPREY_PARAMS, PREDPREY_SRC, PredPreyNP, lq_matrices, lq_source)
+from tests.user_problems import (LOGISTIC2_SRC, LOGISTIC_ROWS_SRC, PREDPREY_PARAMS, PREDPREY_SRC, PROPHARVEST_ROWS_SRC,
+                                 PredPreyNP, PropHarvestNP, lq_matrices, lq_source)
 
 pytestmark = pytest.mark.gpu
 RTOL = 1e-12
@@ -67,6 +68,96 @@ def test_hand_written_logistic2_equals_builtin_and_oracle(ocs, oracle):
     s2 = oracle.fb_sweep(po, [1.0, 1.5], oracle.linspace(0, 8, 161), {"nERROR_PTS": 161, "nINTERP_PTS": 81})
     assert s1["sweeps"][0] == s2["_sweeps"] > 0 and abs(s1["J"][0] - s2["J"]) < 1e-10 * abs(s2["J"])
     assert relerr(s1["u"][:, :, 0], s2["u"]) < 1e-10
+
+
+@pytest.mark.parametrize("nS,N,batch", [(4, 1000, 64), (2, 203, 70), (1, 96, 128), (4, 37, 17)])
+def test_row_separable_user_problem_on_the_fast_mappings(ocs, oracle, nS, N, batch):
+    """A user problem given as ROW functions (hipRTC) runs on the mappings of the registry problems -- the
+    wave-specialised state pass k_forward_p2 and the scan adjoint pass k_backward_scan, instantiated for it -- and on
+    the lane kernels through the derived full-vector methods: all against the oracle (the hand-written LogisticK rows
+    must reproduce the built-in problem), incl. remainders of the 8- / 4-step blockings, ragged tiles, explicit lamT."""
+    import torch
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    c, r = 1.5, 0.05
+    pu = ocs.UserProblem(LOGISTIC_ROWS_SRC, nS, 1, [c, r] + m, BOUNDS, row_separable=True)
+    pb, po = ocs.LogisticProblem(m, c, r, BOUNDS), oracle.LogisticProblem(m, c, r, BOUNDS)
+    rng = np.random.default_rng(10 + nS)
+    t, y = rng.uniform(0, 10, 9), rng.normal(1.5, 0.5, (nS + 1, 9))
+    u, v = rng.uniform(0, 1, (1, 9)), rng.normal(size=(nS + 1, 9))
+    assert relerr(pu.F(t, y, u), po.F(t, y, u)) < 1e-14                      # derived full-vector methods
+    assert relerr(pu.dFdx_times_vec(t, y, u, v), po.dFdx_times_vec(t, y, u, v)) < 1e-14
+    assert relerr(pu.dFdu_times_vec(t, y, u, v), po.dFdu_times_vec(t, y, u, v)) < 1e-14
+    tspan = oracle.linspace(0, 10, N + 1)
+    uu = rng.uniform(0.05, 0.45, (1, 2 * N + 1, batch))
+    x0 = rng.uniform(0.9, 2.0, (nS, batch))
+    ref = oracle.batch_states_adjoints(po, tspan, x0, uu)
+    for mapping in ("auto", "lane"):
+        g = ocs.RK4Integrator(tspan).set_mapping(mapping)
+        x, J = g.compute_states(pu, x0, uu)
+        lam, dJdu = g.compute_adjoints(pu, uu)
+        assert relerr(x, ref["x"]) < RTOL and relerr(J, ref["J"]) < RTOL
+        assert relerr(lam, ref["lam"]) < RTOL and relerr(dJdu, ref["dJdu"]) < RTOL
+        assert np.all(lam[-1] == 1.0)
+        lamT = np.random.default_rng(3).normal(size=(nS + 1, batch))
+        lam2, d2 = g.compute_adjoints(pu, uu, lamT)
+        go = oracle.RK4Integrator(tspan)
+        for b in (0, batch - 1):
+            go.compute_states(po, x0[:, b], uu[:, :, b])
+            lo, do = go.compute_adjoints(po, uu[:, :, b], lamT[:, b])
+            assert relerr(lam2[:, :, b], lo) < RTOL and relerr(d2[:, :, b], do) < RTOL
+    if (nS, N) != (4, 1000):
+        return
+    # BASELINE batch: the row-function instance against the registry problem (same kernels, generic row functions
+    # instead of the shifted logistic form), timing reported and bounded
+    B = 4096
+    dev = torch.device("cuda:0")
+    tspan = np.linspace(0, 10, N + 1)
+    x0d = torch.ones((nS, B), dtype=torch.float64, device=dev)
+    ud = 0.05 + 0.4 * torch.rand((2 * N + 1, 1, B), dtype=torch.float64, device=dev)
+    outs, times = {}, {}
+    for name, prob in (("registry", pb), ("rows", pu)):
+        g = ocs.RK4Integrator(tspan)
+        xd = torch.empty((N + 1, nS + 1, B), dtype=torch.float64, device=dev)
+        lamd, dd = torch.empty_like(xd), torch.empty_like(ud)
+        for _ in range(3):
+            _, Jd = g.compute_states_dev(prob, x0d, ud, xd)
+            g.compute_adjoints_dev(prob, ud, None, lamd, dd)
+        torch.cuda.synchronize()
+        import time
+        t0 = time.perf_counter()
+        for _ in range(20):
+            g.compute_states_dev(prob, x0d, ud, xd)
+            g.compute_adjoints_dev(prob, ud, None, lamd, dd)
+        torch.cuda.synchronize()
+        times[name] = (time.perf_counter() - t0) / 20
+        outs[name] = (xd.cpu().numpy(), lamd.cpu().numpy(), dd.cpu().numpy())
+    for a_, b_ in zip(outs["rows"], outs["registry"]):
+        assert relerr(a_, b_) < 1e-12
+    print(f"pass pair at batch 4096: registry {times['registry']*1e6:.1f} us, row functions {times['rows']*1e6:.1f} us")
+    assert times["rows"] < 1.25 * times["registry"]   # warm: 151 vs 140 us (scripts/user_rows_time.py)
+
+
+def test_row_separable_problem_whose_control_gradient_reads_the_state(ocs, oracle):
+    """x_r' = x_r (m_r - x_r) - u x_r / (1 + r): dF/du depends on y, so the scan kernel recomputes the stage state below
+    each chunk for the chunk's lowest dJdu column; against the NumPy twin of the reference's integrator."""
+    m, c, r = [3.0, 2.5], 1.5, 0.05
+    pu = ocs.UserProblem(PROPHARVEST_ROWS_SRC, 2, 1, [c, r] + m, BOUNDS, row_separable=True)
+    pn = PropHarvestNP(m, c, r)
+    N, batch = 100, 40
+    tspan = oracle.linspace(0, 6, N + 1)
+    rng = np.random.default_rng(5)
+    uu = rng.uniform(0.0, 1.0, (1, 2 * N + 1, batch))
+    x0 = rng.uniform(1.0, 2.5, (2, batch))
+    gn = tw.RK4IntegratorNP(tspan)
+    for mapping in ("auto", "lane"):
+        g = ocs.RK4Integrator(tspan).set_mapping(mapping)
+        x, J = g.compute_states(pu, x0, uu)
+        lam, dJdu = g.compute_adjoints(pu, uu)
+        for b in (0, 1, 39):
+            xn, Jn = gn.compute_states(pn, x0[:, b], uu[:, :, b])
+            lamn, dn = gn.compute_adjoints(pn, uu[:, :, b])
+            assert relerr(x[:, :, b], xn) < RTOL and abs(J[b] - Jn) < RTOL * max(1, abs(Jn))
+            assert relerr(lam[:, :, b], lamn) < RTOL and relerr(dJdu[:, :, b], dn) < RTOL
 
 
 def test_coupled_problem_outside_the_registry(ocs, oracle):

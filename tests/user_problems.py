@@ -24,6 +24,67 @@ __device__ void ocs_ControlChar(double t, const double* x, const double* lam, OC
 }
 """
 
+# ---- LogisticK written as ROW FUNCTIONS (row-separable user problems: the fast mappings of the registry problems) ----
+# params: [c, r, m_1 .. m_NS]; the control cost c u^2 is charged to row 0
+LOGISTIC_ROWS_SRC = r"""
+__device__ double ocs_row_tcoef(double t, OCS_PARAMS p) { return exp(-p[1] * t); }   // hoisted: once per grid point
+__device__ double ocs_row_F(double tc, double y, double u, OCS_PARAMS p, int r) { return y * (p[2 + r] - y) - u; }
+__device__ double ocs_row_q(double tc, double y, double u, OCS_PARAMS p, int r) {
+  return tc * (y * y + (r == 0 ? p[0] * u * u : 0.0));
+}
+__device__ void ocs_row_dFdy(double tc, double y, double u, OCS_PARAMS p, int r, double* dF, double* dq) {
+  *dF = p[2 + r] - 2 * y;
+  *dq = 2 * tc * y;
+}
+__device__ void ocs_row_dFdu(double tc, double y, double u, OCS_PARAMS p, int r, double* dF, double* dq) {
+  *dF = -1.0;
+  *dq = r == 0 ? 2 * p[0] * tc * u : 0.0;
+}
+"""
+
+# a row-separable problem whose control enters multiplicatively (dF/du reads y): x_r' = x_r (m_r - x_r) - u x_r / (1 + r),
+# cost' = e^{-rt} (sum x_r^2 + c u^2);   params [c, r, m_1 .. m_NS]
+PROPHARVEST_ROWS_SRC = r"""
+__device__ double ocs_row_tcoef(double t, OCS_PARAMS p) { return exp(-p[1] * t); }
+__device__ double ocs_row_F(double tc, double y, double u, OCS_PARAMS p, int r) { return y * (p[2 + r] - y) - u * y / (1 + r); }
+__device__ double ocs_row_q(double tc, double y, double u, OCS_PARAMS p, int r) {
+  return tc * (y * y + (r == 0 ? p[0] * u * u : 0.0));
+}
+__device__ void ocs_row_dFdy(double tc, double y, double u, OCS_PARAMS p, int r, double* dF, double* dq) {
+  *dF = p[2 + r] - 2 * y - u / (1 + r);
+  *dq = 2 * tc * y;
+}
+__device__ void ocs_row_dFdu(double tc, double y, double u, OCS_PARAMS p, int r, double* dF, double* dq) {
+  *dF = -y / (1 + r);
+  *dq = r == 0 ? 2 * p[0] * tc * u : 0.0;
+}
+"""
+
+
+class PropHarvestNP:
+    """NumPy twin of PROPHARVEST_ROWS_SRC with the OCProblem method signatures (columns vectorised)."""
+    nC = 1
+
+    def __init__(self, m, c, r):
+        self.m, self.c, self.r = np.asarray(m, dtype=np.float64), float(c), float(r)
+        self.nS = self.m.size
+        self.sc = 1.0 / (1 + np.arange(self.nS))
+
+    def F(self, t, y, u):
+        x = y[:self.nS]
+        f = x * (self.m[:, None] - x) - u[0] * x * self.sc[:, None]
+        return np.vstack([f, np.exp(-self.r * t) * (np.sum(x * x, axis=0) + self.c * u[0] * u[0])])
+
+    def dFdx_times_vec(self, t, y, u, v):
+        x = y[:self.nS]
+        g = (self.m[:, None] - 2 * x - u[0] * self.sc[:, None]) * v[:self.nS] + 2 * np.exp(-self.r * t) * x * v[self.nS]
+        return np.vstack([g, np.zeros_like(g[:1])])
+
+    def dFdu_times_vec(self, t, y, u, v):
+        x = y[:self.nS]
+        return (np.sum(-x * self.sc[:, None] * v[:self.nS], axis=0) + 2 * self.c * np.exp(-self.r * t) * u[0] * v[self.nS])[None, :]
+
+
 # ---- predator-prey with harvested predator: coupled, not row-separable, not in the registry ----
 # x1' = x1 (al - be x2),  x2' = x2 (de x1 - ga) - u x2,  cost' = e^{-rt} (c u^2 + q (x1 - xb)^2)
 # params: [al, be, de, ga, c, q, xb, r]
