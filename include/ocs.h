@@ -255,8 +255,10 @@ typedef struct ocs_fbs_options {
   int nINTERP_PTS; /* :22 */
   int fused_update_off; /* build option, default 0: with the error points on the grid nodes the convergence metric is
                            taken inside the control update, and the pchip midpoints of x are formed inside the costate
-                           and control kernels; 1 keeps all of them separate kernels, 2 only the midpoints (same
-                           results to round-off) */
+                           and control kernels, and from the second sweep on the control update runs inside the state
+                           pass (which reads the costate of the sweep before) and the convergence test inside the costate
+                           pass; 1 keeps all of them separate kernels, 2 only the midpoints, 3 only the control update
+                           of sweeps >= 2 (same results to round-off) */
   int nWINDOWS;         /* build option, default 0 = automatic (currently 1): with the fused update the batch can be cut
                            into this many windows that run their sweep loops on separate streams (marching kernels of
                            one window under the streaming kernels of another); results do not depend on it */

@@ -391,7 +391,8 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // Error points on the grid nodes and the default start: the control at the error points is the node samples of the
   // grid control, so the weighted change is taken while the grid control is replaced (one kernel, one pass over x and
   // lam) instead of in a separate error-point kernel with its own copy of the control.
-  const bool fusedup = f->err_on_nodes && !u0grid && opt->fused_update_off != 1;
+  const int fuo = opt->fused_update_off == 3 ? 0 : opt->fused_update_off;   // 3: as 0, without the fold below
+  const bool fusedup = f->err_on_nodes && !u0grid && fuo != 1;
   const int nparts = fusedup ? control_grid_parts(N) : control_pts_parts(nE);
   OCS_TRY(f->metric.ensure(sizeof(double) * (size_t)nparts * B));
   OCS_TRY(f->anyvalid.ensure(sizeof(int) * B));
@@ -510,7 +511,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // start with a look at sweep k's device counter: if no instance was left, they return at once (a sweep over
   // converged instances would change nothing anyway -- they are frozen -- but would cost its full time).
   bool spec_done = false;
-  if (fusedup && nwin == 1 && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch) &&
+  if (fusedup && nwin == 1 && fuo == 0 && costate_forms_midpoints(pd, N, batch) &&
       forward_gate_supported(pd, gd, batch)) {
     const int nsw = opt->nSWEEPS;
     if (f->h_nact_cap < nsw) {
@@ -527,8 +528,22 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     OCS_TRY(f->nact_slots.ensure(sizeof(int) * (size_t)nsw));
     HIP_TRY(hipMemsetAsync(f->nact_slots.p, 0, sizeof(int) * (size_t)nsw, s));
     int* dslots = (int*)f->nact_slots.p;
+    // Sweeps >= 2 with the control update folded into the state pass (ocs_fold_kernel.hpp): the control a sweep
+    // integrates is ControlChar of the costate of the sweep before, formed inside the pass; the costate pass measures
+    // the change of the control its new costate implies and takes the convergence decision.  Two kernels per sweep,
+    // and the grid samples of u are neither written nor read.
+    const bool fold = opt->fused_update_off == 0 && fold_supported(pd, gd, batch);
     auto enqueue = [&](int sweep) -> int {
       const int* gate = sweep > 1 ? dslots + (sweep - 2) : nullptr;  // active instances after the sweep before
+      if (fold && sweep > 1) {
+        LAUNCH_TRY(launch_forward_cc(pd, gd, batch, tb.PR, p->d_lb.d(), p->d_ub.d(), x0, lam, xaug, J, status,
+                                     opt->cost_row == 0, gate, s));
+        LAUNCH_TRY(launch_costate_met(pd, gd, batch, xaug, nAug, tb.PR, p->d_lb.d(), p->d_ub.d(), opt->uRelTol,
+                                      opt->uAbsTol, sweep, status, mc, dslots + (sweep - 1), lam, s, gate));
+        HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(f->wevents[sweep & 1], s));
+        return OCS_OK;
+      }
       FwdOpts fo;
       fo.frozen = status;
       fo.dump = f->dump.d();
@@ -564,7 +579,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     fo.no_cost_row = opt->cost_row == 0;  // soln holds x, lam, u and the scalar J (fb_sweep.m:117-125)
     LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
     // pchip midpoints of x: inside the costate and control kernels where the wave-specialised costate kernel applies
-    const bool ownx = fusedup && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch);
+    const bool ownx = fusedup && fuo == 0 && costate_forms_midpoints(pd, N, batch);
     const double* xmid = ownx ? nullptr : f->xmid.d();
     if (!ownx) LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s));
     HIP_TRY(hipMemsetAsync(f->nactive.p, 0, sizeof(int), s));

@@ -1,0 +1,384 @@
+// ocs_fold_kernel.hpp -- state pass of sweep k >= 2 of the forward-backward sweep with the control update folded in.
+//
+// fb_sweep.m:79-87 alternates  [x, lam] = compute_x_lam(u)  and  u = ControlChar(t, x(t), lam(t))  on the grid.  For the
+// problems of the wave-specialised kernels ControlChar does not read x, so the control a state pass integrates is a
+// function of the PREVIOUS sweep's costate alone: u_k(t) = ControlChar(t, lam_{k-1}(t)), with lam at the half steps by
+// pchip (compute_x_lam.m:11-14 / vectorInterpolant).  Writing those 2N+1 samples per instance to memory and reading
+// them back was the largest kernel of a sweep (k_control_grid: 24 B per instance and step written, 8 + 8 read);
+// here the state pass reads the costate rows instead (8 B) and forms its control samples on the way:
+//
+//   wave M    streams the step records, the pchip interval records, the ControlChar time coefficients and the node rows
+//             of lam of a block of D = 8 steps HBM -> LDS (LDS-DMA), Q blocks ahead;
+//   waves U   (D / G of them) take one step of a block each, lane (step, trajectory), in two stages one interval apart:
+//             the pchip slope at the step's right node (block k+3; each slope is formed once and handed on through
+//             LDS), then lam at the half step from the two slopes, ControlChar at the half step and at the right
+//             node (block k+2) -> ubuf (the layout the control samples have when they come from memory);
+//   waves P, S, C, J   exactly as in k_forward_p2 (ocs_pipeline2_kernel.hpp), reading ubuf instead of a DMA slot.
+//
+// Interval k (between barriers k and k+1), k = -3 .. nb+1:
+//   M: issues block k+5+Q, waits for block k+5     U: slopes of block k+3, samples of block k+2     P: block k+1
+//   S: block k     C: block k-1     J: block k-2
+// A block's slot is read from interval j-4 (the slopes of block j-1 take its first two nodes) to j+1 (C): NSLOT = Q + 7.
+// The arithmetic of S, C and J is k_forward_p2's; the control samples agree with k_control_grid's to round-off (the
+// same pchip formulas, the interval records of k_costate_plx instead of the node tables).
+#pragma once
+#include "ocs_pipeline2_kernel.hpp"
+
+namespace ocs {
+
+template <int G>
+struct FoldCfg {
+  static constexpr int D = 8, TPW = 64 / G;
+  static constexpr int Q = 5;
+  static constexpr int NSLOT = Q + 7;
+  static constexpr int RS = rec_stride(1), SCO = rec_sc_offset(1);
+  static constexpr int REC_DBL = D * RS;                       // step records
+  static constexpr int LAM_DBL = D * 64, NLAM = LAM_DBL / 128; // node rows of lam, [node][row][trajectory]
+  static constexpr int PR_DBL = D * kPRec;                     // pchip interval records
+  static constexpr int TU_DBL = 32;                            // ControlChar coefficients of grid points 2jD .. 2jD+31
+                                                               // (a DMA instruction with lanes 0..15 only)
+  static constexpr int LOFF = REC_DBL, POFF = LOFF + LAM_DBL, TOFF = POFF + PR_DBL;
+  static constexpr int SLOT = TOFF + TU_DBL;
+  static constexpr int LPB = REC_DBL / 128 + NLAM + PR_DBL / 128 + 1;
+  static constexpr int KHEAD = -3;                             // first interval
+  static constexpr int U_DBL = 2 * D * TPW;
+  static constexpr int NCW = (G == 4) ? 2 : 4;
+  static constexpr int SPW = D / NCW;
+  static constexpr int NPASS = SPW / G > 0 ? SPW / G : 1;
+  static constexpr int NUW = D / G;                            // control waves: G steps per wave
+  static constexpr int NWAVE = 4 + NCW + NUW;
+  static_assert(REC_DBL == 128 && PR_DBL == 128 && Q * LPB <= 63, "block shapes");
+  // wave -> role: the recursion wave shares its SIMD (waves w, w+4, w+8, w+12) with the light roles only
+  enum Role { M_ = 0, S_ = 1, P_ = 2, J_ = 3, C_ = 4, U_ = 5 };
+  __device__ static constexpr int role(int w) {
+    return G == 1 ? (w == 1 ? S_ : w == 5 ? P_ : w == 9 ? J_ : w == 13 ? M_ : (w == 0 || (w >= 2 && w <= 4)) ? C_ : U_)
+         : G == 2 ? (w == 0 ? M_ : w == 1 ? S_ : w == 5 ? P_ : w == 9 ? J_ : (w == 2 || w == 3 || w == 4 || w == 6) ? C_ : U_)
+                  : (w == 0 ? M_ : w == 1 ? S_ : w == 5 ? P_ : w == 4 ? J_ : (w == 2 || w == 3) ? C_ : U_);
+  }
+  __device__ static constexpr int index_in_role(int w) {   // how many waves below w have w's role
+    int n = 0;
+    for (int v = 0; v < w; ++v) n += role(v) == role(w);
+    return n;
+  }
+};
+
+struct FwdArgsCC {
+  int N, batch;
+  const double* REC;
+  const double* PR;     // [N][kPRec]
+  const double* TU;     // [2N+1 (+32 readable)] ControlChar-side time coefficients (NTU = 1)
+  const double* ps;
+  const double* pb;
+  unsigned pmask;
+  const double* lb;     // [NC]
+  const double* ub;
+  const double* x0;
+  const double* lam;    // [N+1][G][B] costate of the sweep before
+  double* x;
+  double* J;
+  const int* frozen;
+  int nocost;
+  const int* gate;
+};
+
+template <class P, bool UNI>
+__global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const FwdArgsCC a) {
+  constexpr int G = P::NS, NAUG = P::NAUG;
+  static_assert(P::NC == 1 && P::NTC == 1 && P::NTU == 1 && P::HAS_SHIFT, "fold: one control, shifted row form");
+  using C_ = FoldCfg<G>;
+  constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
+  constexpr int NCW = C_::NCW, SPW = C_::SPW;
+  __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];
+  __shared__ __attribute__((aligned(16))) double ubuf[4][C_::U_DBL];      // control samples of a block: [2s | 2s+1][trajectory]
+  __shared__ __attribute__((aligned(16))) double zb[2][D][64];
+  __shared__ double ufirst[4][TPW];
+  __shared__ double ufirst0[TPW];                                         // u(t_0)
+  __shared__ __attribute__((aligned(16))) double dsl[4][D][64];           // pchip slope of lam at the right node of a step
+  __shared__ double dnode0[64];                                           // ... at t_0
+  __shared__ __attribute__((aligned(16))) double2 prep[2][D][64];
+  __shared__ double dd[2][D][TPW];
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  const size_t B = (size_t)a.batch;
+  const int N = a.N, nb = N / D;
+  const int bw = blockIdx.x * TPW;
+  if (a.gate && *a.gate == 0) return;
+  const uniform_ptr PS = as_uniform(a.ps);
+  const size_t colB = (size_t)NAUG * B;
+  const int role = C_::role(wave);
+
+  if (role == C_::M_) {
+    // ---------------- M: HBM -> LDS ----------------
+    // blocks 0 .. nb; block nb is the node t_N alone (its other rows repeat it, its tables are block nb-1's)
+    auto issue = [&](int j) OCS_INLINE {
+      double* dst = &inp[j % NSLOT][0];
+      const int jt = j < nb ? j : nb - 1;
+      dma16_p2(a.REC + (size_t)jt * C_::REC_DBL + 2 * lane, dst);
+#pragma unroll
+      for (int q = 0; q < C_::NLAM; ++q) {
+        const int e = q * 128 + 2 * lane, st = e / 64, rr = (e % 64) / TPW, t2 = e % TPW;
+        const int node = j * D + st < N ? j * D + st : N;
+        dma16_p2(a.lam + ((size_t)node * G + rr) * B + bw + t2, dst + C_::LOFF + q * 128);
+      }
+      dma16_p2(a.PR + (size_t)jt * C_::PR_DBL + 2 * lane, dst + C_::POFF);
+      if (lane < C_::TU_DBL / 2) dma16_p2(a.TU + (size_t)jt * 2 * D + 2 * lane, dst + C_::TOFF);
+    };
+    // before barrier k the blocks <= k+4 have landed
+    const int youngest0 = (1 + Q) < nb ? (1 + Q) : nb;
+    for (int j = 0; j <= youngest0; ++j) issue(j);
+    wait_blocks_p2<C_::LPB, Q>(youngest0 - 1);
+    for (int k = C_::KHEAD; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      if (k + 5 + Q <= nb) issue(k + 5 + Q);
+      if (k + 5 <= nb) {
+        const int youngest = (k + 5 + Q) < nb ? (k + 5 + Q) : nb;
+        wait_blocks_p2<C_::LPB, Q>(youngest - (k + 5));
+      }
+    }
+  } else if (role == C_::U_) {
+    // ---------------- U: the control samples of block k+2 from the costate of the sweep before ----------------
+    const int sub = lane / TPW, tl = lane % TPW, b = bw + tl;
+    const typename P::Par par = P::load(ParamSrc{PS, a.pb, a.pmask, B, b});
+    const typename P::CCPre ccp = P::cc_pre(par);
+    const double lb = a.lb[0], ub = a.ub[0];
+    int uwi = 0;   // this wave's index among the U waves (wave-uniform)
+    for (int v = 0; v < wave; ++v) uwi += C_::role(v) == C_::U_;
+    const int s = uwi * G + sub;              // this lane's step of every block
+    for (int k = C_::KHEAD; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      // ---- slopes: node n = js D + s + 1, the right node of this lane's step of block js = k + 3 ----
+      const int js = k + 3;
+      if (js < nb) {
+        const double* slot = &inp[js % NSLOT][0];
+        const double* nxt = &inp[(js + 1) % NSLOT][0];
+        const int n = js * D + s + 1;
+        const double* pr = slot + C_::POFF + s * kPRec;   // record of interval n-1
+        const double ih0 = pr[4], ih1 = pr[5], W1 = pr[8], W2 = pr[9];
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+          const int o = C_::LOFF + r * TPW + tl;
+          const double wa = slot[o + s * 64];                                                  // node n-1
+          const double wb = s + 1 < D ? slot[o + (s + 1) * 64] : nxt[o];                       // node n
+          const double wc = s + 2 < D ? slot[o + (s + 2) * 64] : nxt[o + (s + 2 - D) * 64];    // node n+1 (or a valid address)
+          const double sa = (wb - wa) * ih0, sb = (wc - wb) * ih1;
+          double d = pchip_interior_s(sa, sb, W1, W2);
+          if (n == N) {   // right end: three-point formula on the last two intervals
+            const double wz = slot[o + (D - 2) * 64];   // node n-2 (n == N: the last step of the last block)
+            d = pchip_end_pl(pr[1], pr[0], sa, (wa - wz) * pr[3]);
+          }
+          dsl[js % 4][s][r * TPW + tl] = d;
+          if (n == 1) {   // left end: the slope at t_0
+            dnode0[r * TPW + tl] = pchip_end_pl(pr[1], pr[2], sa, sb);
+          }
+        }
+      }
+      // ---- samples: lam at the half step of interval i = jm D + s (block jm = k + 2), ControlChar there and at node i+1 ----
+      const int jm = k + 2;
+      if (jm < 0 || jm >= nb) continue;
+      {
+        const double* slot = &inp[jm % NSLOT][0];
+        const double* nxt = &inp[(jm + 1) % NSLOT][0];
+        const double* pr = slot + C_::POFF + s * kPRec;
+        const double ih0 = pr[4], sv = pr[10];
+        const double tuM = slot[C_::TOFF + 2 * s + 1], tuB = slot[C_::TOFF + 2 * s + 2];
+        double lmid[G], lnode[G];
+#pragma unroll
+        for (int r = 0; r < G; ++r) {
+          const int o = C_::LOFF + r * TPW + tl;
+          const double w1 = slot[o + s * 64];
+          const double w2 = s + 1 < D ? slot[o + (s + 1) * 64] : nxt[o];
+          const double d1 = dsl[jm % 4][s][r * TPW + tl];
+          const double dprev = s > 0 ? dsl[jm % 4][s > 0 ? s - 1 : 0][r * TPW + tl] : dsl[(jm + 3) % 4][D - 1][r * TPW + tl];
+          const double d0 = (jm == 0 && s == 0) ? dnode0[r * TPW + tl] : dprev;
+          const double sec1 = (w2 - w1) * ih0;
+          const double dzzdx = (sec1 - d0) * ih0, dzdxdx = (d1 - sec1) * ih0;
+          const double c3 = (dzdxdx - dzzdx) * ih0, c2 = 2.0 * dzzdx - dzdxdx;
+          lmid[r] = w1 + sv * (d0 + sv * (c2 + sv * c3));
+          lnode[r] = w2;
+        }
+        double* us = &ubuf[jm % 4][tl];
+        us[(2 * s) * TPW] = P::control_char_pre(tuM, lmid, ccp, lb, ub);
+        us[(2 * s + 1) * TPW] = P::control_char_pre(tuB, lnode, ccp, lb, ub);
+        if (jm == 0 && s == 0) {   // the first node of the horizon
+          double l0[G];
+#pragma unroll
+          for (int r = 0; r < G; ++r) l0[r] = slot[C_::LOFF + r * TPW + tl];
+          ufirst0[tl] = P::control_char_pre(slot[C_::TOFF], l0, ccp, lb, ub);
+        }
+      }
+    }
+  } else if (role == C_::S_) {
+    // ---------------- S: the recursion (k_forward_p2's) ----------------
+    const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
+    const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
+    const bool fz = a.frozen != nullptr && a.frozen[b] != 0;
+    const double mh = P::row_shift(rp);
+    double z = a.x0[(size_t)r * B + b] - mh;
+    double cprev = 0.0;
+    const uniform_ptr R0 = as_uniform(a.REC);
+    const double hU = R0[0], hhU = R0[1], h6U = R0[2];
+    for (int k = C_::KHEAD; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      if (k == -1) cprev = P::row_vertex(mh, ufirst0[tl]);   // written by U in interval -2
+      if (k >= 0 && k < nb) {
+        const double* rec = &inp[k % NSLOT][0];
+        const double2* pw = &prep[k & 1][0][lane];
+        double* zw = &zb[k & 1][0][lane];
+        struct In { double2 c; double h, hh, h6; };
+        auto fetch = [&](int s) OCS_INLINE {
+          In v;
+          v.c = pw[s * 64];
+          if (!UNI) {
+            v.h = rec[RS * s];
+            v.hh = rec[RS * s + 1];
+            v.h6 = rec[RS * s + 2];
+          } else {
+            v.h = hU; v.hh = hhU; v.h6 = h6U;
+          }
+          return v;
+        };
+        In nxt = fetch(0);
+#pragma unroll
+        for (int s = 0; s < D; ++s) {
+          const In c = nxt;
+          if (s + 1 < D) nxt = fetch(s + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          const double cM = c.c.x, cB = c.c.y;
+          zw[s * 64] = z;
+          const double F1 = P::row_f_shifted(z, cprev);
+          double Z = __builtin_fma(c.hh, F1, z);
+          const double F2 = P::row_f_shifted(Z, cM);
+          Z = __builtin_fma(c.hh, F2, z);
+          const double F3 = P::row_f_shifted(Z, cM);
+          Z = __builtin_fma(c.h, F3, z);
+          const double F4 = P::row_f_shifted(Z, cB);
+          z = __builtin_fma(c.h6, F4, __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)), z));
+          cprev = cB;
+        }
+      }
+    }
+    if (!fz) a.x[((size_t)N * NAUG + r) * B + b] = z + mh;
+  } else if (role == C_::C_) {
+    // ---------------- C: objective increments and the stores of the trajectory (k_forward_p2's) ----------------
+    int cw = 0;
+    for (int v = 0; v < wave; ++v) cw += C_::role(v) == C_::C_;
+    const int csub = lane / TPW, ctl = lane % TPW, b = bw + ctl;
+    typename P::RowPar rpr[G];
+    double mhr[G];
+#pragma unroll
+    for (int q = 0; q < G; ++q) {
+      rpr[q] = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, q);
+      mhr[q] = P::row_shift(rpr[q]);
+    }
+    const bool fz = a.frozen != nullptr && a.frozen[b] != 0;
+    const unsigned B8 = (unsigned)(B * 8), col8 = (unsigned)(colB * 8);
+    const unsigned vx = fz ? kDropP2 : (unsigned)((size_t)b * 8) + (unsigned)csub * col8;
+    const uniform_ptr R0 = as_uniform(a.REC);
+    const double hU = R0[0], hhU = R0[1];
+    for (int k = C_::KHEAD; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      if (k >= 1 && k <= nb) {
+        const int j = k - 1;
+        const double* rec = &inp[j % NSLOT][0];
+        const double* us = &ubuf[j % 4][ctl];
+        const double* zr = &zb[j & 1][0][0];
+        const double ublk = ufirst[j % 4][ctl];
+        const BufP2 bx = BufP2::make(a.x + (size_t)(j * D) * colB);
+#pragma unroll
+        for (int p = 0; p < C_::NPASS; ++p) {
+          const int s0 = cw * SPW + p * G;
+          const int s = s0 + csub;
+          const double wA = rec[RS * s + SCO + 3], wM = rec[RS * s + SCO + 4], wB = rec[RS * s + SCO + 5];
+          const double h = UNI ? hU : rec[RS * s], hh = UNI ? hhU : rec[RS * s + 1];
+          const double uM = us[(2 * s) * TPW], uB = us[(2 * s + 1) * TPW];
+          const double uAl = us[(s > 0 ? 2 * s - 1 : 0) * TPW];
+          const double uA = s > 0 ? uAl : ublk;
+          double zq[G];
+#pragma unroll
+          for (int q = 0; q < G; ++q) zq[q] = zr[s * 64 + q * TPW + ctl];
+          const double uA2 = uA * uA, uM2 = uM * uM, uB2 = uB * uB;
+          const double cqM = P::control_q(uM2, rpr[0]);
+          double q1 = P::control_q(uA2, rpr[0]), q2 = cqM, q3 = cqM, q4 = P::control_q(uB2, rpr[0]);
+#pragma unroll
+          for (int q = 0; q < G; ++q) {
+            const double z = zq[q], mh = mhr[q];
+            const double cA = P::row_vertex(mh, uA), cM = P::row_vertex(mh, uM);
+            const double F1 = P::row_f_shifted(z, cA);
+            const double Z2 = __builtin_fma(hh, F1, z);
+            const double F2 = P::row_f_shifted(Z2, cM);
+            const double Z3 = __builtin_fma(hh, F2, z);
+            const double F3 = P::row_f_shifted(Z3, cM);
+            const double Z4 = __builtin_fma(h, F3, z);
+            const double y1 = z + mh;
+            q1 = P::state_q_acc(y1, q1);
+            q2 = P::state_q_acc(Z2 + mh, q2);
+            q3 = P::state_q_acc(Z3 + mh, q3);
+            q4 = P::state_q_acc(Z4 + mh, q4);
+            bx.st(y1, vx, (unsigned)s0 * col8 + (unsigned)q * B8);
+          }
+          const double d = __builtin_fma(wA, q1, __builtin_fma(wM, q2 + q3, wB * q4));
+          if (csub < G) dd[j & 1][s][ctl] = d;
+        }
+      }
+    }
+  } else if (role == C_::J_) {
+    // ---------------- J: running objective (k_forward_p2's) ----------------
+    constexpr int SPJ = D / G;
+    const int sg = lane / TPW, tl = lane % TPW, b = bw + tl;
+    const bool fz = a.frozen != nullptr && a.frozen[b] != 0;
+    const bool wc = !a.nocost;
+    const unsigned col8 = (unsigned)(colB * 8);
+    const unsigned vj = (fz || !wc) ? kDropP2 : (unsigned)(((size_t)G * B + b) * 8) + (unsigned)(sg * SPJ + 1) * col8;
+    double carry = 0.0;
+    if (wc && !fz && sg == 0) a.x[(size_t)G * B + b] = 0.0;
+    for (int k = C_::KHEAD; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      if (k >= 2) {
+        const int j = k - 2;
+        double pre[SPJ];
+#pragma unroll
+        for (int q = 0; q < SPJ; ++q) pre[q] = dd[j & 1][sg * SPJ + q][tl];
+#pragma unroll
+        for (int q = 1; q < SPJ; ++q) pre[q] += pre[q - 1];
+        const double tot = pre[SPJ - 1];
+        double excl = 0.0;
+        if (G >= 2) {
+          const int below = (lane + 64 - TPW) & 63;
+          const double t1 = __shfl(tot, below);
+          double inc = tot + (sg >= 1 ? t1 : 0.0);
+          if (G == 4) {
+            const double t2 = __shfl(inc, (lane + 64 - 2 * TPW) & 63);
+            inc += (sg >= 2 ? t2 : 0.0);
+          }
+          const double e = __shfl(inc, below);
+          excl = sg >= 1 ? e : 0.0;
+        }
+        const double base = carry + excl;
+        const BufP2 bx = BufP2::make(a.x + (size_t)(j * D) * colB);
+#pragma unroll
+        for (int q = 0; q < SPJ; ++q) bx.st_nt(base + pre[q], vj, (unsigned)q * col8);
+        const double lastv = base + pre[SPJ - 1];
+        carry = (G == 1) ? lastv : __shfl(lastv, (G - 1) * TPW + tl);
+      }
+    }
+    if (!fz && sg == 0) a.J[b] = carry;
+  } else {
+    // ---------------- P: the control terms of the next block for S, and the node before a block for C ----------------
+    const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
+    const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
+    const double mh = P::row_shift(rp);
+    for (int k = C_::KHEAD; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      const int j = k + 1;   // read by S in interval k+1; its samples were written by U in interval k-1
+      if (j < 0 || j >= nb) continue;
+      const double* us = &ubuf[j % 4][tl];
+      double2* w = &prep[j & 1][0][lane];
+#pragma unroll
+      for (int s = 0; s < D; ++s)
+        w[s * 64] = double2{P::row_vertex(mh, us[(2 * s) * TPW]), P::row_vertex(mh, us[(2 * s + 1) * TPW])};
+      if (lane < TPW) ufirst[j % 4][lane] = j > 0 ? ubuf[(j - 1) % 4][(2 * D - 1) * TPW + lane] : ufirst0[lane];
+    }
+  }
+}
+
+}  // namespace ocs

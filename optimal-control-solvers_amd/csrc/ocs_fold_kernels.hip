@@ -1,0 +1,40 @@
+// ocs_fold_kernels.hip -- launcher of the state pass that forms its control from the costate of the sweep before
+// (ocs_fold_kernel.hpp); registry problems whose ControlChar does not read x.
+#include "ocs_fold_kernel.hpp"
+#include "ocs_internal.hpp"
+#include "ocs_problems.hpp"
+
+namespace ocs {
+
+static inline int hip_rc7(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
+
+bool fold_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
+  if (p.functor != Functor::Logistic || p.nC != 1 || !(p.nS == 1 || p.nS == 2 || p.nS == 4)) return false;
+  return g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 && costate_forms_midpoints(p, g.N, batch) && g.TU && g.REC;
+}
+
+template <class P>
+static void run_forward_cc(const FwdArgsCC& a, bool uniform, hipStream_t s) {
+  using C_ = FoldCfg<P::NS>;
+  const dim3 grid(a.batch / C_::TPW), block(C_::NWAVE * 64);
+  if (uniform)
+    k_forward_cc<P, true><<<grid, block, 0, s>>>(a);
+  else
+    k_forward_cc<P, false><<<grid, block, 0, s>>>(a);
+}
+
+int launch_forward_cc(const ProblemDesc& p, const GridDesc& g, int batch, const double* PR, const double* lb,
+                      const double* ub, const double* x0, const double* lam, double* x, double* J, const int* frozen,
+                      bool no_cost_row, const int* gate, hipStream_t s) {
+  if (!fold_supported(p, g, batch) || !PR || !lam || !x || !J) return -1;
+  const FwdArgsCC a{g.N, batch, g.REC, PR, g.TU, p.ps, p.pb, p.pmask, lb, ub, x0, lam, x, J, frozen, no_cost_row ? 1 : 0, gate};
+  if (p.nS == 1)
+    run_forward_cc<LogisticK<1>>(a, g.uniform, s);
+  else if (p.nS == 2)
+    run_forward_cc<LogisticK<2>>(a, g.uniform, s);
+  else
+    run_forward_cc<LogisticK<4>>(a, g.uniform, s);
+  return hip_rc7(hipGetLastError());
+}
+
+}  // namespace ocs

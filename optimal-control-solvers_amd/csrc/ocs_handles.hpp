@@ -229,7 +229,8 @@ inline int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStr
     const int ntc = functor_ntc(p->functor, p->nS);
     const int ntu = functor_ntu(p->functor, p->nS);
     OCS_TRY(g->d_TC.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * ntc));
-    OCS_TRY(g->d_TU.ensure(sizeof(double) * (size_t)(2 * g->N + 1) * (ntu > 0 ? ntu : 1)));
+    // (+128: the fold kernels stream this table in 1 KiB pieces, the last of which reaches past the horizon)
+    OCS_TRY(g->d_TU.ensure(sizeof(double) * ((size_t)(2 * g->N + 1) * (ntu > 0 ? ntu : 1) + 128)));
     g->rec_stride = rec_stride_host(ntc);
     OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)(g->N + 2 * rec_pad_host()) * g->rec_stride));
     LAUNCH_TRY(launch_tcoef(describe(p), describe(g), s));

@@ -180,6 +180,15 @@ struct FbsTables {   // pchip node tables of an integrator grid, device pointers
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s,
                      int ldb = 0);
 bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch);
+// fb_sweep with the control update folded into the state pass (ocs_fold_kernel.hpp) and the convergence test into the
+// costate pass (k_costate_plx, MET): sweeps >= 2 are two kernels
+bool fold_supported(const ProblemDesc& p, const GridDesc& g, int batch);
+int launch_forward_cc(const ProblemDesc& p, const GridDesc& g, int batch, const double* PR, const double* lb,
+                      const double* ub, const double* x0, const double* lam, double* x, double* J, const int* frozen,
+                      bool no_cost_row, const int* gate, hipStream_t s);
+int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                       const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
+                       double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb = 0,
                    const double* PR = nullptr,   // xmid == NULL with PR: the kernel forms the midpoints (see below)

@@ -996,34 +996,39 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
 //   slot of block j is read in intervals j (one node, by H for block j-1), j+1 (H), j+2 (two nodes by H for block
 //   j+1; L) and rewritten by M in interval j+NSLOT-Q  ->  NSLOT = Q + 3.
 // ---------------------------------------------------------------------------------------
-constexpr int kPRec = 16;  // doubles per interval record {h(i-1),h(i),h(i+1), 1/h x3, W1(i),W2(i),W1(i+1),W2(i+1), tmid-t(i), pad}
-template <int G>
+// (kPRec, the interval record layout, and pchip_end_pl are in ocs_device_common.hpp)
+// MET: the pass also measures the change of the control its costate implies (see k_costate_plx): the costate rows of
+// the sweep before and the ControlChar time coefficients of the block ride along in the slot, which lives one interval longer
+template <int G, bool MET = false>
 struct CostateXCfg {
-  static constexpr int D = 8, TPW = 64 / G, Q = 3, NSLOT = Q + 3;
+  static constexpr int D = 8, TPW = 64 / G, Q = 3, NSLOT = Q + 3 + (MET ? 1 : 0);
   static constexpr int RS = rec_stride(1);
   static constexpr int REC_DBL = D * RS, NREC = REC_DBL / 128;
   static constexpr int PR_DBL = D * kPRec, NPR = PR_DBL / 128;
   static constexpr int X_DBL = D * 64, NX = X_DBL / 128;
-  static constexpr int SLOT = REC_DBL + PR_DBL + X_DBL;
-  static constexpr int LPB = NREC + NPR + NX;
+  static constexpr int LOFF = REC_DBL + PR_DBL + X_DBL, TUOFF = LOFF + X_DBL;   // MET only
+  static constexpr int SLOT = REC_DBL + PR_DBL + X_DBL + (MET ? X_DBL + 128 : 0);
+  static constexpr int LPB = NREC + NPR + NX + (MET ? NX + 1 : 0);
   static_assert(PR_DBL % 128 == 0, "interval records of a block must be whole DMA instructions");
 };
 struct CostateXArgs {
   CostateArgsPL c;     // c.xmid is not used
   const double* PR;    // [N][kPRec]
   const int* gate;     // optional: the launch does nothing if *gate == 0
+  // MET (fb_sweep with the control update folded into the state pass, ocs_fold_kernel.hpp): c.lam holds the costate of the
+  // sweep before on entry.  The weighted change of the control at the nodes (fb_sweep.m:107), ControlChar(lam_new)
+  // against ControlChar(lam_old), is taken while lam is replaced, and check_convergence + the loop bookkeeping
+  // (:79-87, :99-115; k_fbs_advance) are done by the same wave at the end: c.frozen is the status array.
+  const double* TU;    // [2N+1 (+128 readable)] ControlChar-side time coefficients (NTU = 1)
+  const double* lb;
+  const double* ub;
+  double relTol, absTol;
+  int sweep;
+  int* status;         // == c.frozen
+  double* maxChange;   // [nSWEEPS][B]
+  int* nactive;        // counter of the instances that continue
 };
 
-__device__ static inline double pchip_end_pl(double h0, double h1, double del0, double del1) {
-  double d = ((2.0 * h0 + h1) * del0 - h0 * del1) / (h0 + h1);
-  const bool s0 = (d > 0.0) == (del0 > 0.0) && (d < 0.0) == (del0 < 0.0);
-  const bool s1 = (del0 > 0.0) == (del1 > 0.0) && (del0 < 0.0) == (del1 < 0.0);
-  if (!s0)
-    d = 0.0;
-  else if (!s1 && fabs(d) > fabs(3.0 * del0))
-    d = 3.0 * del0;
-  return d;
-}
 
 // one helper wave of k_costate_plx: the pchip midpoints of intervals q0 .. q0+RL-1 (ascending positions) of every block;
 // ST: this wave also stores the costate values the recursion wave leaves in LDS (lr), so that the recursion wave
@@ -1090,11 +1095,11 @@ __device__ static inline void costate_midpoints(const double (*inp)[C_::SLOT], d
   }
 }
 
-template <class P, bool FRZ>
-__global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
+template <class P, bool FRZ, bool MET = false>
+__global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXArgs aa) {
   constexpr int G = P::NS;
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
-  using C_ = CostateXCfg<G>;
+  using C_ = CostateXCfg<G, MET>;
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS;
   constexpr int POFF = C_::REC_DBL, XOFF = C_::REC_DBL + C_::PR_DBL;
   const CostateArgsPL& a = aa.c;
@@ -1120,7 +1125,10 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
       for (int q = 0; q < C_::NX; ++q) {
         const int e = q * 128 + 2 * lane, st = e / 64, rr = (e % 64) / TPW, tl = e % TPW;
         dma16(a.x + ((size_t)(iLo + st) * a.ldx + rr) * B + bw + tl, dst + XOFF + q * 128);
+        // the costate of the sweep before, read Q blocks ahead of the stores that replace it (three intervals behind)
+        if (MET) dma16(a.lam + ((size_t)(iLo + st) * G + rr) * B + bw + tl, dst + C_::LOFF + q * 128);
       }
+      if (MET) dma16(aa.TU + (size_t)2 * iLo + 2 * lane, dst + C_::TUOFF);
     };
     for (int j = 0; j < Q && j < nb; ++j) issue(j);
     for (int k = 0; k <= nb + 2; ++k) {
@@ -1135,6 +1143,71 @@ __global__ __launch_bounds__(320) void k_costate_plx(const CostateXArgs aa) {
   }
   const int r = lane % G, tl = lane / G;
   const int b = bw + tl;
+  if (MET && wave == 5) {
+    // ---------------- X: the change of the control at the nodes, then check_convergence for this trajectory ----------------
+    // lane (trajectory tl, steps r, r+G, .. of a block): all rows of a node, new (lr, left by L) and old (the slot)
+    const uniform_ptr PS = as_uniform(a.ps);
+    const typename P::CCPre ccp = P::cc_pre(P::load(ParamSrc{PS, a.pb, a.pmask, B, b}));
+    const double lb = aa.lb[0], ub = aa.ub[0];
+    double nmax = 0.0, dmax = 1.0;   // the largest weighted change as a fraction (k_control_grid's bookkeeping)
+    bool any = false;
+    auto take = [&](double un, double uo) OCS_INLINE {
+      const double n = fabs(un - uo), d = aa.relTol * fabs(uo) + aa.absTol;
+      const bool valid = (n == n) & (d == d) & !((n == 0.0) & (d == 0.0));   // n / d is not NaN (max() skips NaN, :108)
+      const bool rep = valid & (!any | (n * dmax > nmax * d));
+      nmax = rep ? n : nmax;
+      dmax = rep ? d : dmax;
+      any = any | valid;
+    };
+    if (r == 0) {   // node t_N: lam = 0 before and after
+      double z[G];
+#pragma unroll
+      for (int q = 0; q < G; ++q) z[q] = 0.0;
+      const double u0 = P::control_char_pre(aa.TU[(size_t)2 * N], z, ccp, lb, ub);
+      take(u0, u0);
+    }
+    for (int k = 0; k <= nb + 2; ++k) {
+      lds_barrier();
+      const int j = k - 3;
+      if (j < 0) continue;
+      const double* slot = &inp[j % NSLOT][0];
+#pragma unroll
+      for (int s0 = 0; s0 < D; s0 += G) {
+        const int s = s0 + r, q = D - 1 - s;
+        double ln[G], lo[G];
+#pragma unroll
+        for (int qq = 0; qq < G; ++qq) {
+          ln[qq] = lr[j & 1][s][tl * G + qq];
+          lo[qq] = slot[C_::LOFF + q * 64 + qq * TPW + tl];
+        }
+        const double tu = slot[C_::TUOFF + 2 * q];
+        take(P::control_char_pre(tu, ln, ccp, lb, ub), P::control_char_pre(tu, lo, ccp, lb, ub));
+      }
+    }
+#pragma unroll
+    for (int m = 1; m < G; m <<= 1) {   // over the lanes of the trajectory
+      const double on = __shfl_xor(nmax, m), od = __shfl_xor(dmax, m);
+      const bool oa = __shfl_xor((int)any, m) != 0;
+      if (oa && (!any || on * dmax > nmax * od)) {
+        nmax = on;
+        dmax = od;
+      }
+      any = any || oa;
+    }
+    // fb_sweep.m:108-110 and :79-87 (k_fbs_advance): every other wave of this workgroup read the status when it started
+    bool still = false;
+    if (r == 0 && aa.status[b] == 0) {
+      const double mx = any ? nmax / dmax : __builtin_nan("");
+      aa.maxChange[(size_t)(aa.sweep - 1) * B + b] = mx;
+      if (mx <= 1.0)
+        aa.status[b] = aa.sweep;
+      else
+        still = true;
+    }
+    const unsigned long long mk = __ballot(still);
+    if (lane == 0 && mk) atomicAdd(aa.nactive, __popcll(mk));
+    return;
+  }
   const double xN = a.x[((size_t)N * a.ldx + r) * B + b];  // x(t_N): the node above the first block
   if (wave != 3) {
     // ---------------- H0, H1, H2: pchip midpoints of intervals 0-2, 3-5, 6-7 of every block ----------------
@@ -1228,6 +1301,25 @@ int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const
     run_costate_plx<LogisticK<2>>(a, s);
   else if (p.nS == 4)
     run_costate_plx<LogisticK<4>>(a, s);
+  else
+    return -1;
+  return hip_rc5(hipGetLastError());
+}
+
+// costate pass + change of the control + check_convergence (CostateXArgs, MET); lam holds the costate of the sweep before
+int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                       const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
+                       double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate) {
+  if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || !PR || !g.TU || !status || !maxChange || !nactive) return -1;
+  const CostateXArgs a{CostateArgsPL{g.N, batch, 0, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, status, nullptr, lam},
+                       PR, gate, g.TU, lb, ub, relTol, absTol, sweep, status, maxChange, nactive};
+  const dim3 grid(batch / (64 / p.nS)), block(384);
+  if (p.nS == 1)
+    k_costate_plx<LogisticK<1>, true, true><<<grid, block, 0, s>>>(a);
+  else if (p.nS == 2)
+    k_costate_plx<LogisticK<2>, true, true><<<grid, block, 0, s>>>(a);
+  else if (p.nS == 4)
+    k_costate_plx<LogisticK<4>, true, true><<<grid, block, 0, s>>>(a);
   else
     return -1;
   return hip_rc5(hipGetLastError());

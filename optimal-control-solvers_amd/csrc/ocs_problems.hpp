@@ -188,6 +188,19 @@ struct LogisticK {
     const double v = s * tu[0] / (2.0 * p.c);
     u[0] = fmin(ub[0], fmax(lb[0], v));
   }
+  // the same with the division hoisted out of a loop over grid points (kernels that evaluate ControlChar per step on a
+  // wave with an instruction budget: k_forward_cc, k_costate_plx): one rounding more than control_char
+  static constexpr bool CC_READS_X = false;
+  struct CCPre {
+    double inv2c;
+  };
+  __device__ static inline CCPre cc_pre(const Par& p) { return CCPre{1.0 / (2.0 * p.c)}; }
+  __device__ static inline double control_char_pre(double tu, const double* lam, const CCPre& c, double lb, double ub) {
+    double s = lam[0];
+#pragma unroll
+    for (int k = 1; k < NS; ++k) s += lam[k];
+    return fmin(ub, fmax(lb, s * tu * c.inv2c));
+  }
 };
 
 }  // namespace ocs

@@ -11,13 +11,14 @@ cs = rng.uniform(1.0, 2.0, batch)
 prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
 prob.set_batch_params([0], cs[None, :])
 integ = ocs.RK4Integrator(ocs.linspace(0, 10, 1001))
+OPTS = {"fused_update_off": int(os.environ["FUO"])} if "FUO" in os.environ else None
 for _ in range(3):
-    r = ocs.fb_sweep_dev(prob, integ, x0)
+    r = ocs.fb_sweep_dev(prob, integ, x0, OPTS)
 torch.cuda.synchronize()
 for rep in range(3):
     t0 = time.perf_counter()
     for _ in range(5):
-        r = ocs.fb_sweep_dev(prob, integ, x0)
+        r = ocs.fb_sweep_dev(prob, integ, x0, OPTS)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / 5
     sw = r["sweeps"].cpu().numpy()

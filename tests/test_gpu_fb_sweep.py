@@ -160,6 +160,14 @@ def test_fused_costate_update_equals_separate_kernels(ocs, oracle, nS, N, batch)
             assert relerr(ra[key], rw[key]) < 1e-12, key
         assert relerr(np.nan_to_num(ra["maxChange"]), np.nan_to_num(rw["maxChange"])) < 1e-6
         assert np.array_equal(np.isnan(ra["maxChange"]), np.isnan(rw["maxChange"]))
+    # ... without the fold of the control update into the state pass of the next sweep (option 3: sweeps >= 2 are
+    # forward, costate, control update, advance instead of forward-with-ControlChar, costate-with-convergence-test)
+    rd = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=3))
+    assert np.array_equal(ra["sweeps"], rd["sweeps"])
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rd[key]) < 1e-12, key
+    assert relerr(np.nan_to_num(ra["maxChange"]), np.nan_to_num(rd["maxChange"])) < 1e-6
+    assert np.array_equal(np.isnan(ra["maxChange"]), np.isnan(rd["maxChange"]))
     # ... and with the pchip midpoints of x from their own kernel instead of inside the costate / control kernels
     rc = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=2))
     assert np.array_equal(ra["sweeps"], rc["sweeps"])
@@ -173,6 +181,31 @@ def test_fused_costate_update_equals_separate_kernels(ocs, oracle, nS, N, batch)
     for key in ("x", "lam", "u", "J"):
         assert relerr(ra[key], rb[key]) < 1e-12, key
     for b in sorted({0, batch // 2, batch - 1}):
+        ref = oracle.fb_sweep(oracle.LogisticProblem(m, cs[b], P["r"], BOUNDS), x0[:, b], tspan, base)
+        assert ra["sweeps"][b] == ref["_sweeps"]
+        assert abs(ra["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
+        assert relerr(ra["x"][:, :, b], ref["x"]) < RTOL and relerr(ra["lam"][:, :, b], ref["lam"]) < RTOL
+        assert relerr(ra["u"][:, :, b], ref["u"]) < RTOL
+
+
+@pytest.mark.parametrize("nS,N,batch", [(1, 64, 64), (2, 96, 64), (4, 40, 32)])
+def test_fold_on_a_bitwise_uniform_grid(ocs, oracle, nS, N, batch):
+    """Step 2^-5: every step size is the same bit pattern, so the state pass keeps h, h/2, h/6 in registers (another
+    instance of the kernel that forms its control from the costate of the sweep before)."""
+    rng = np.random.default_rng(N + nS)
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    tspan = np.arange(N + 1) / 32.0
+    x0 = rng.uniform(0.8, 2.0, (nS, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    base = {"nERROR_PTS": N + 1, "nINTERP_PTS": 33, "nSWEEPS": 40}
+    ra = ocs.fb_sweep_batch(prob, x0, tspan, dict(base))
+    rd = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=3))
+    assert np.array_equal(ra["sweeps"], rd["sweeps"]) and ra["sweeps"].min() > 0
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rd[key]) < 1e-12, key
+    for b in (0, batch - 1):
         ref = oracle.fb_sweep(oracle.LogisticProblem(m, cs[b], P["r"], BOUNDS), x0[:, b], tspan, base)
         assert ra["sweeps"][b] == ref["_sweeps"]
         assert abs(ra["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
