@@ -127,6 +127,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     const int youngest0 = (1 + Q) < nb ? (1 + Q) : nb;
     for (int j = 0; j <= youngest0; ++j) issue(j);
     wait_blocks_p2<C_::LPB, Q>(youngest0 - 1);
+    P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k + 5 + Q <= nb) issue(k + 5 + Q);
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         wait_blocks_p2<C_::LPB, Q>(youngest - (k + 5));
       }
     }
+    P2_END(wave);
   } else if (role == C_::U_) {
     // ---------------- U: the control samples of block k+2 from the costate of the sweep before ----------------
     const int sub = lane / TPW, tl = lane % TPW, b = bw + tl;
@@ -144,6 +146,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     int uwi = 0;   // this wave's index among the U waves (wave-uniform)
     for (int v = 0; v < wave; ++v) uwi += C_::role(v) == C_::U_;
     const int s = uwi * G + sub;              // this lane's step of every block
+    P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       // ---- slopes: node n = js D + s + 1, the right node of this lane's step of block js = k + 3 ----
@@ -207,6 +210,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         }
       }
     }
+    P2_END(wave);
   } else if (role == C_::S_) {
     // ---------------- S: the recursion (k_forward_p2's) ----------------
     const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
@@ -217,6 +221,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     double cprev = 0.0;
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1], h6U = R0[2];
+    P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k == -1) cprev = P::row_vertex(mh, ufirst0[tl]);   // written by U in interval -2
@@ -257,6 +262,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         }
       }
     }
+    P2_END(wave);
     if (!fz) a.x[((size_t)N * NAUG + r) * B + b] = z + mh;
   } else if (role == C_::C_) {
     // ---------------- C: objective increments and the stores of the trajectory (k_forward_p2's) ----------------
@@ -275,6 +281,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     const unsigned vx = fz ? kDropP2 : (unsigned)((size_t)b * 8) + (unsigned)csub * col8;
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1];
+    P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k >= 1 && k <= nb) {
@@ -321,6 +328,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         }
       }
     }
+    P2_END(wave);
   } else if (role == C_::J_) {
     // ---------------- J: running objective (k_forward_p2's) ----------------
     constexpr int SPJ = D / G;
@@ -331,6 +339,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     const unsigned vj = (fz || !wc) ? kDropP2 : (unsigned)(((size_t)G * B + b) * 8) + (unsigned)(sg * SPJ + 1) * col8;
     double carry = 0.0;
     if (wc && !fz && sg == 0) a.x[(size_t)G * B + b] = 0.0;
+    P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k >= 2) {
@@ -361,12 +370,14 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         carry = (G == 1) ? lastv : __shfl(lastv, (G - 1) * TPW + tl);
       }
     }
+    P2_END(wave);
     if (!fz && sg == 0) a.J[b] = carry;
   } else {
     // ---------------- P: the control terms of the next block for S, and the node before a block for C ----------------
     const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
     const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
     const double mh = P::row_shift(rp);
+    P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       const int j = k + 1;   // read by S in interval k+1; its samples were written by U in interval k-1
@@ -378,6 +389,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         w[s * 64] = double2{P::row_vertex(mh, us[(2 * s) * TPW]), P::row_vertex(mh, us[(2 * s + 1) * TPW])};
       if (lane < TPW) ufirst[j % 4][lane] = j > 0 ? ubuf[(j - 1) % 4][(2 * D - 1) * TPW + lane] : ufirst0[lane];
     }
+    P2_END(wave);
   }
 }
 

@@ -3,6 +3,7 @@
 #include "ocs_fold_kernel.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_problems.hpp"
+#include <cstdio>
 
 namespace ocs {
 
@@ -34,6 +35,22 @@ int launch_forward_cc(const ProblemDesc& p, const GridDesc& g, int batch, const 
     run_forward_cc<LogisticK<2>>(a, g.uniform, s);
   else
     run_forward_cc<LogisticK<4>>(a, g.uniform, s);
+#ifdef OCS_P2_STAMPS
+  {
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      (void)hipStreamSynchronize(s);
+      long long h[64];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p2_stamp), sizeof(h));
+      fprintf(stderr, "[fold fwd nS=%d] cycles (barrier wait / total):", p.nS);
+      for (int w = 0; w < 16; ++w) fprintf(stderr, " w%d %lld/%lld", w, h[4 * w], h[4 * w + 1]);
+      static long long hw[4096];
+      (void)hipMemcpyFromSymbol(hw, HIP_SYMBOL(g_p2_wg), sizeof(hw));
+      fprintf(stderr, "\n   workgroup 0: %lld cycles in %lld ticks of 10 ns = %.3f GHz\n", hw[1] - hw[0], hw[3],
+              (double)(hw[1] - hw[0]) / (10.0 * hw[3]));
+    }
+  }
+#endif
   return hip_rc7(hipGetLastError());
 }
 

@@ -33,7 +33,7 @@
 namespace ocs {
 
 #ifdef OCS_P2_STAMPS
-__device__ static long long g_p2_stamp[8 * 4];   // per wave role: {barrier wait, total, -, -} of workgroup 0
+__device__ static long long g_p2_stamp[16 * 4];   // per wave role: {barrier wait, total, -, -} of workgroup 0
 __device__ static long long g_p2_wg[1024 * 4];    // per workgroup: S wave {start, end, barrier wait, xcc}
 #define P2_BARRIER() do { const long long t0_ = __builtin_amdgcn_s_memtime(); lds_barrier_p2_(); tbar_ += __builtin_amdgcn_s_memtime() - t0_; } while (0)
 #define P2_BEGIN() long long tbar_ = 0; const long long tstart_ = __builtin_amdgcn_s_memtime(); const long long rstart_ = __builtin_amdgcn_s_memrealtime()

@@ -1096,7 +1096,7 @@ __device__ static inline void costate_midpoints(const double (*inp)[C_::SLOT], d
 }
 
 template <class P, bool FRZ, bool MET = false>
-__global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXArgs aa) {
+__global__ __launch_bounds__(MET ? 576 : 320) void k_costate_plx(const CostateXArgs aa) {
   constexpr int G = P::NS;
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels are written for one control and one time coefficient");
   using C_ = CostateXCfg<G, MET>;
@@ -1106,6 +1106,7 @@ __global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXA
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];
   __shared__ __attribute__((aligned(16))) double xm[2][D][64];
   __shared__ __attribute__((aligned(16))) double lr[2][D][64];  // L -> H2: lam of a block, for the stores
+  __shared__ double xres[MET ? 3 : 1][3][64];                   // MET: the partial maxima of the X waves
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
@@ -1139,13 +1140,21 @@ __global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXA
       lds_barrier();
       if (k + Q < nb) issue(k + Q);
     }
+    if (MET) lds_barrier();   // the X waves exchange their partial maxima
     return;
   }
   const int r = lane % G, tl = lane / G;
   const int b = bw + tl;
-  if (MET && wave == 5) {
-    // ---------------- X: the change of the control at the nodes, then check_convergence for this trajectory ----------------
-    // lane (trajectory tl, steps r, r+G, .. of a block): all rows of a node, new (lr, left by L) and old (the slot)
+  if (MET && wave == 7) {   // keeps the recursion wave alone on its SIMD (waves w, w + 4, ..): takes part in the barriers only
+    for (int k = 0; k <= nb + 3; ++k) lds_barrier();
+    return;
+  }
+  if (MET && wave >= 5) {
+    // ---------------- X0..X2: the change of the control at the nodes, then check_convergence for this trajectory -------
+    // (waves 5, 6, 8: steps 0-2, 3-5, 6-7 of every block; one per SIMD beside the recursion wave's)
+    // lane (trajectory tl, every G-th step of the wave's share): all rows of a node, new (lr, left by L) and old (the slot)
+    const int xw = wave == 5 ? 0 : (wave == 6 ? 1 : 2);
+    const int sLo = xw * 3, sCnt = xw == 2 ? 2 : 3;
     const uniform_ptr PS = as_uniform(a.ps);
     const typename P::CCPre ccp = P::cc_pre(P::load(ParamSrc{PS, a.pb, a.pmask, B, b}));
     const double lb = aa.lb[0], ub = aa.ub[0];
@@ -1153,13 +1162,13 @@ __global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXA
     bool any = false;
     auto take = [&](double un, double uo) OCS_INLINE {
       const double n = fabs(un - uo), d = aa.relTol * fabs(uo) + aa.absTol;
-      const bool valid = (n == n) & (d == d) & !((n == 0.0) & (d == 0.0));   // n / d is not NaN (max() skips NaN, :108)
+      const bool valid = (n + d) > 0.0;   // n / d is not NaN: neither is one, and they are not both zero (max() skips NaN, :108)
       const bool rep = valid & (!any | (n * dmax > nmax * d));
       nmax = rep ? n : nmax;
       dmax = rep ? d : dmax;
       any = any | valid;
     };
-    if (r == 0) {   // node t_N: lam = 0 before and after
+    if (r == 0 && xw == 0) {   // node t_N: lam = 0 before and after
       double z[G];
 #pragma unroll
       for (int q = 0; q < G; ++q) z[q] = 0.0;
@@ -1172,8 +1181,9 @@ __global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXA
       if (j < 0) continue;
       const double* slot = &inp[j % NSLOT][0];
 #pragma unroll
-      for (int s0 = 0; s0 < D; s0 += G) {
-        const int s = s0 + r, q = D - 1 - s;
+      for (int c0 = 0; c0 < 3; c0 += G) {
+        if (c0 + r >= sCnt) continue;
+        const int s = sLo + c0 + r, q = D - 1 - s;
         double ln[G], lo[G];
 #pragma unroll
         for (int qq = 0; qq < G; ++qq) {
@@ -1188,6 +1198,23 @@ __global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXA
     for (int m = 1; m < G; m <<= 1) {   // over the lanes of the trajectory
       const double on = __shfl_xor(nmax, m), od = __shfl_xor(dmax, m);
       const bool oa = __shfl_xor((int)any, m) != 0;
+      if (oa && (!any || on * dmax > nmax * od)) {
+        nmax = on;
+        dmax = od;
+      }
+      any = any || oa;
+    }
+    if (xw > 0 && r == 0) {
+      xres[xw][0][tl] = nmax;
+      xres[xw][1][tl] = dmax;
+      xres[xw][2][tl] = any ? 1.0 : 0.0;
+    }
+    lds_barrier();
+    if (xw > 0) return;
+#pragma unroll
+    for (int w = 1; w < 3; ++w) {
+      const double on = xres[w][0][tl], od = xres[w][1][tl];
+      const bool oa = xres[w][2][tl] != 0.0;
       if (oa && (!any || on * dmax > nmax * od)) {
         nmax = on;
         dmax = od;
@@ -1219,6 +1246,7 @@ __global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXA
     else  // the helper with the shortest run also stores lam
       costate_midpoints<C_, 2, true>(inp, xm, 6, N, r, tl, lane, xN, lr, a.lam + (size_t)r * B + b, (size_t)G * B,
                                      FRZ && a.frozen[b] != 0);
+    if (MET) lds_barrier();
     return;
   }
   // ---------------- L: costate recursion ----------------
@@ -1278,6 +1306,7 @@ __global__ __launch_bounds__(MET ? 384 : 320) void k_costate_plx(const CostateXA
       bB = bA;
     }
   }
+  if (MET) lds_barrier();
 }
 
 template <class P>
@@ -1313,7 +1342,7 @@ int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const
   if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || !PR || !g.TU || !status || !maxChange || !nactive) return -1;
   const CostateXArgs a{CostateArgsPL{g.N, batch, 0, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, status, nullptr, lam},
                        PR, gate, g.TU, lb, ub, relTol, absTol, sweep, status, maxChange, nactive};
-  const dim3 grid(batch / (64 / p.nS)), block(384);
+  const dim3 grid(batch / (64 / p.nS)), block(576);
   if (p.nS == 1)
     k_costate_plx<LogisticK<1>, true, true><<<grid, block, 0, s>>>(a);
   else if (p.nS == 2)
