@@ -86,6 +86,21 @@ __device__ static inline double pchip_interior_s(double del0, double del1, doubl
   return pr > 0.0 ? d : 0.0;
 }
 
+// ... and with the quotient by reciprocal + Newton steps instead of the IEEE division sequence (no scaling: the secants of
+// a costate are far from the ends of the exponent range; at most an ulp from the correctly rounded quotient)
+__device__ static inline double fast_div(double n, double d) {
+  double r = __builtin_amdgcn_rcp(d);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
+  const double q = n * r;
+  return __builtin_fma(__builtin_fma(-d, q, n), r, q);
+}
+__device__ static inline double pchip_interior_f(double del0, double del1, double w1, double w2) {
+  const double pr = del0 * del1;
+  const double d = fast_div(pr, __builtin_fma(w1, del0, w2 * del1));
+  return pr > 0.0 ? d : 0.0;
+}
+
 // per-interval pchip records of the node grid (built by k_pchip_records, streamed by k_costate_plx / k_forward_cc):
 // doubles per interval i: {h(i-1), h(i), h(i+1), 1/h(i-1), 1/h(i), 1/h(i+1), W1(i), W2(i), W1(i+1), W2(i+1), tmid_i - t_i, pad}
 constexpr int kPRec = 16;

@@ -34,12 +34,13 @@ struct FoldCfg {
   static constexpr int RS = rec_stride(1), SCO = rec_sc_offset(1);
   static constexpr int REC_DBL = D * RS;                       // step records
   static constexpr int LAM_DBL = D * 64, NLAM = LAM_DBL / 128; // node rows of lam, [node][row][trajectory]
-  static constexpr int PR_DBL = D * kPRec;                     // pchip interval records
-  static constexpr int TU_DBL = 32;                            // ControlChar coefficients of grid points 2jD .. 2jD+31
-                                                               // (a DMA instruction with lanes 0..15 only)
+  // pchip interval records and ControlChar coefficients (grid points 2jD .. 2jD+31: a DMA instruction with lanes 0..15
+  // only) of a block -- G > 1 only: on G == 1 the control waves read them with scalar loads from the tables
+  static constexpr int PR_DBL = G == 1 ? 0 : D * kPRec;
+  static constexpr int TU_DBL = G == 1 ? 0 : 32;
   static constexpr int LOFF = REC_DBL, POFF = LOFF + LAM_DBL, TOFF = POFF + PR_DBL;
   static constexpr int SLOT = TOFF + TU_DBL;
-  static constexpr int LPB = REC_DBL / 128 + NLAM + PR_DBL / 128 + 1;
+  static constexpr int LPB = REC_DBL / 128 + NLAM + (G == 1 ? 0 : 2);
   static constexpr int KHEAD = -3;                             // first interval
   static constexpr int U_DBL = 2 * D * TPW;
   static constexpr int NCW = (G == 4) ? 2 : 4;
@@ -47,7 +48,7 @@ struct FoldCfg {
   static constexpr int NPASS = SPW / G > 0 ? SPW / G : 1;
   static constexpr int NUW = D / G;                            // control waves: G steps per wave
   static constexpr int NWAVE = 4 + NCW + NUW;
-  static_assert(REC_DBL == 128 && PR_DBL == 128 && Q * LPB <= 63, "block shapes");
+  static_assert(REC_DBL == 128 && (G == 1 || PR_DBL == 128) && Q * LPB <= 63, "block shapes");
   // wave -> role: the recursion wave shares its SIMD (waves w, w+4, w+8, w+12) with the light roles only
   enum Role { M_ = 0, S_ = 1, P_ = 2, J_ = 3, C_ = 4, U_ = 5 };
   __device__ static constexpr int role(int w) {
@@ -110,8 +111,10 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
   if (role == C_::M_) {
     // ---------------- M: HBM -> LDS ----------------
     // blocks 0 .. nb; block nb is the node t_N alone (its other rows repeat it, its tables are block nb-1's)
+    int cI = 0;   // ring position of the next block to issue (blocks are issued in order)
     auto issue = [&](int j) OCS_INLINE {
-      double* dst = &inp[j % NSLOT][0];
+      double* dst = &inp[0][0] + cI * C_::SLOT;
+      cI = cI + 1 == NSLOT ? 0 : cI + 1;
       const int jt = j < nb ? j : nb - 1;
       dma16_p2(a.REC + (size_t)jt * C_::REC_DBL + 2 * lane, dst);
 #pragma unroll
@@ -120,8 +123,10 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         const int node = j * D + st < N ? j * D + st : N;
         dma16_p2(a.lam + ((size_t)node * G + rr) * B + bw + t2, dst + C_::LOFF + q * 128);
       }
-      dma16_p2(a.PR + (size_t)jt * C_::PR_DBL + 2 * lane, dst + C_::POFF);
-      if (lane < C_::TU_DBL / 2) dma16_p2(a.TU + (size_t)jt * 2 * D + 2 * lane, dst + C_::TOFF);
+      if constexpr (G > 1) {
+        dma16_p2(a.PR + (size_t)jt * C_::PR_DBL + 2 * lane, dst + C_::POFF);
+        if (lane < C_::TU_DBL / 2) dma16_p2(a.TU + (size_t)jt * 2 * D + 2 * lane, dst + C_::TOFF);
+      }
     };
     // before barrier k the blocks <= k+4 have landed
     const int youngest0 = (1 + Q) < nb ? (1 + Q) : nb;
@@ -146,69 +151,108 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     int uwi = 0;   // this wave's index among the U waves (wave-uniform)
     for (int v = 0; v < wave; ++v) uwi += C_::role(v) == C_::U_;
     const int s = uwi * G + sub;              // this lane's step of every block
+    // The two stages of an interval are independent (the samples use the slopes of the interval before).  The LDS pipe
+    // is the contended unit of this kernel, so whatever the samples stage needs that the slopes stage of the interval
+    // before has already read or formed -- the two node values of the step, its own slope, the spacing -- is carried in
+    // registers, and on G == 1, where a wave's step is the same for all lanes, the interval records and the ControlChar
+    // coefficients are scalar loads from the tables in memory (constant cache) instead of LDS broadcasts.
+    const int rowA = s * 64;                                    // node at the left of the step, in its block's slot
+    const bool inB = s + 1 < D, inC = s + 2 < D;                // the next two nodes: same slot, or the first rows of the next
+    const int rowB = (inB ? s + 1 : s + 1 - D) * 64, rowC = (inC ? s + 2 : s + 2 - D) * 64;
+    // ring positions of the blocks k+3, k+4, carried along (a wave's time goes into its instruction count, and the
+    // remainders of a ring of 12 were a large part of it); a block outside the horizon still has a position: what is
+    // read there is not used
+    int c3 = 0, c4 = 1;   // k = KHEAD = -3: blocks 0, 1
+    static_assert(C_::KHEAD == -3, "ring positions at the first interval");
+    const uniform_ptr PRu = as_uniform(a.PR), TUu = as_uniform(a.TU);
+    double cw1[G], cw2[G], cd1[G];          // carried: nodes i, i+1 and the slope at i+1 of the step whose samples come next
+    double cih = 0.0, csv = 0.0, ctuM = 0.0, ctuB = 0.0, ctu0 = 0.0;
+#pragma unroll
+    for (int r = 0; r < G; ++r) cw1[r] = cw2[r] = cd1[r] = 0.0;
     P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
-      // ---- slopes: node n = js D + s + 1, the right node of this lane's step of block js = k + 3 ----
-      const int js = k + 3;
-      if (js < nb) {
-        const double* slot = &inp[js % NSLOT][0];
-        const double* nxt = &inp[(js + 1) % NSLOT][0];
+      const int js = k + 3, jm = k + 2;
+#if defined(OCS_FOLD_ABL) && OCS_FOLD_ABL == 1
+      if (jm >= 0 && jm < nb) { ubuf[jm & 3][tl + (2 * s) * TPW] = 0.3; ubuf[jm & 3][tl + (2 * s + 1) * TPW] = 0.3; ufirst0[tl] = 0.3; }
+      continue;
+#endif
+      const bool vs = js < nb, vm = (unsigned)jm < (unsigned)nb;
+      // ---- slopes: node n = js D + s + 1, the right node of this lane's step of block js ----
+      const double* slotS = &inp[0][0] + c3 * C_::SLOT;
+      const double* nxtS = &inp[0][0] + c4 * C_::SLOT;
+      c3 = c4;
+      c4 = c4 + 1 == NSLOT ? 0 : c4 + 1;
+      double ih0, ih1, W1, W2, svn, tuMn, tuBn, tu0n, hE0 = 0.0, hE1 = 0.0, hE2 = 0.0, ihE = 0.0;
+      const bool ends = vs && (js == 0 || js == nb - 1);   // a block with an end of the grid: the three-point formulas
+      if constexpr (G == 1) {
+        const int i = vs ? js * D + s : 0;                  // (wave-uniform)
+        const uniform_ptr q = PRu + (size_t)i * kPRec;
+        ih0 = q[4]; ih1 = q[5]; W1 = q[8]; W2 = q[9]; svn = q[10];
+        tu0n = TUu[2 * i]; tuMn = TUu[2 * i + 1]; tuBn = TUu[2 * i + 2];
+        if (ends) { hE0 = q[0]; hE1 = q[1]; hE2 = q[2]; ihE = q[3]; }
+      } else {
+        const double* prS = slotS + C_::POFF + s * kPRec;   // record of interval n-1
+        ih0 = prS[4]; ih1 = prS[5]; W1 = prS[8]; W2 = prS[9]; svn = prS[10];
+        tu0n = slotS[C_::TOFF + 2 * s]; tuMn = slotS[C_::TOFF + 2 * s + 1]; tuBn = slotS[C_::TOFF + 2 * s + 2];
+        if (ends) { hE0 = prS[0]; hE1 = prS[1]; hE2 = prS[2]; ihE = prS[3]; }
+      }
+      const bool first = jm == 0 && s == 0;
+      double wa[G], wb[G], wc[G], d0[G];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        const int o = C_::LOFF + r * TPW + tl;
+        wa[r] = slotS[o + rowA];
+        wb[r] = (inB ? slotS : nxtS)[o + rowB];
+        wc[r] = (inC ? slotS : nxtS)[o + rowC];   // (beyond t_N: a valid address, the value is not used)
+        // the slope at the left node of the samples' step: the neighbouring wave's, of the interval before
+        d0[r] = (s > 0 ? dsl[jm & 3][s > 0 ? s - 1 : 0] : dsl[(jm + 3) & 3][D - 1])[r * TPW + tl];
+      }
+      if (jm == 0) {   // (wave-uniform)
+#pragma unroll
+        for (int r = 0; r < G; ++r) d0[r] = first ? dnode0[r * TPW + tl] : d0[r];
+      }
+      double dn[G], lmid[G];
+#pragma unroll
+      for (int r = 0; r < G; ++r) {
+        const double sa = (wb[r] - wa[r]) * ih0, sb = (wc[r] - wb[r]) * ih1;
+        dn[r] = pchip_interior_f(sa, sb, W1, W2);
+        const double sec1 = (cw2[r] - cw1[r]) * cih;
+        const double dzzdx = (sec1 - d0[r]) * cih, dzdxdx = (cd1[r] - sec1) * cih;
+        const double c3_ = (dzdxdx - dzzdx) * cih, c2_ = 2.0 * dzzdx - dzdxdx;
+        lmid[r] = cw1[r] + csv * (d0[r] + csv * (c2_ + csv * c3_));
+      }
+      const double uM = P::control_char_pre(ctuM, lmid, ccp, lb, ub), uB = P::control_char_pre(ctuB, cw2, ccp, lb, ub);
+      if (vm) {
+        double* us = &ubuf[jm & 3][tl];
+        us[(2 * s) * TPW] = uM;
+        us[(2 * s + 1) * TPW] = uB;
+        if (first) ufirst0[tl] = P::control_char_pre(ctu0, cw1, ccp, lb, ub);   // the first node of the horizon
+      }
+      if (ends) {
         const int n = js * D + s + 1;
-        const double* pr = slot + C_::POFF + s * kPRec;   // record of interval n-1
-        const double ih0 = pr[4], ih1 = pr[5], W1 = pr[8], W2 = pr[9];
 #pragma unroll
         for (int r = 0; r < G; ++r) {
-          const int o = C_::LOFF + r * TPW + tl;
-          const double wa = slot[o + s * 64];                                                  // node n-1
-          const double wb = s + 1 < D ? slot[o + (s + 1) * 64] : nxt[o];                       // node n
-          const double wc = s + 2 < D ? slot[o + (s + 2) * 64] : nxt[o + (s + 2 - D) * 64];    // node n+1 (or a valid address)
-          const double sa = (wb - wa) * ih0, sb = (wc - wb) * ih1;
-          double d = pchip_interior_s(sa, sb, W1, W2);
-          if (n == N) {   // right end: three-point formula on the last two intervals
-            const double wz = slot[o + (D - 2) * 64];   // node n-2 (n == N: the last step of the last block)
-            d = pchip_end_pl(pr[1], pr[0], sa, (wa - wz) * pr[3]);
+          const double sa = (wb[r] - wa[r]) * ih0, sb = (wc[r] - wb[r]) * ih1;
+          if (n == N) {
+            const double wz = slotS[C_::LOFF + r * TPW + tl + (D - 2) * 64];   // node N-2 (n == N: the last step of the last block)
+            dn[r] = pchip_end_pl(hE1, hE0, sa, (wa[r] - wz) * ihE);
           }
-          dsl[js % 4][s][r * TPW + tl] = d;
-          if (n == 1) {   // left end: the slope at t_0
-            dnode0[r * TPW + tl] = pchip_end_pl(pr[1], pr[2], sa, sb);
-          }
+          if (n == 1) dnode0[r * TPW + tl] = pchip_end_pl(hE1, hE2, sa, sb);   // the slope at t_0
         }
       }
-      // ---- samples: lam at the half step of interval i = jm D + s (block jm = k + 2), ControlChar there and at node i+1 ----
-      const int jm = k + 2;
-      if (jm < 0 || jm >= nb) continue;
-      {
-        const double* slot = &inp[jm % NSLOT][0];
-        const double* nxt = &inp[(jm + 1) % NSLOT][0];
-        const double* pr = slot + C_::POFF + s * kPRec;
-        const double ih0 = pr[4], sv = pr[10];
-        const double tuM = slot[C_::TOFF + 2 * s + 1], tuB = slot[C_::TOFF + 2 * s + 2];
-        double lmid[G], lnode[G];
 #pragma unroll
-        for (int r = 0; r < G; ++r) {
-          const int o = C_::LOFF + r * TPW + tl;
-          const double w1 = slot[o + s * 64];
-          const double w2 = s + 1 < D ? slot[o + (s + 1) * 64] : nxt[o];
-          const double d1 = dsl[jm % 4][s][r * TPW + tl];
-          const double dprev = s > 0 ? dsl[jm % 4][s > 0 ? s - 1 : 0][r * TPW + tl] : dsl[(jm + 3) % 4][D - 1][r * TPW + tl];
-          const double d0 = (jm == 0 && s == 0) ? dnode0[r * TPW + tl] : dprev;
-          const double sec1 = (w2 - w1) * ih0;
-          const double dzzdx = (sec1 - d0) * ih0, dzdxdx = (d1 - sec1) * ih0;
-          const double c3 = (dzdxdx - dzzdx) * ih0, c2 = 2.0 * dzzdx - dzdxdx;
-          lmid[r] = w1 + sv * (d0 + sv * (c2 + sv * c3));
-          lnode[r] = w2;
-        }
-        double* us = &ubuf[jm % 4][tl];
-        us[(2 * s) * TPW] = P::control_char_pre(tuM, lmid, ccp, lb, ub);
-        us[(2 * s + 1) * TPW] = P::control_char_pre(tuB, lnode, ccp, lb, ub);
-        if (jm == 0 && s == 0) {   // the first node of the horizon
-          double l0[G];
-#pragma unroll
-          for (int r = 0; r < G; ++r) l0[r] = slot[C_::LOFF + r * TPW + tl];
-          ufirst0[tl] = P::control_char_pre(slot[C_::TOFF], l0, ccp, lb, ub);
-        }
+      for (int r = 0; r < G; ++r) {
+        if (vs) dsl[js & 3][s][r * TPW + tl] = dn[r];
+        cw1[r] = wa[r];
+        cw2[r] = wb[r];
+        cd1[r] = dn[r];
       }
+      cih = ih0;
+      csv = svn;
+      ctuM = tuMn;
+      ctuB = tuBn;
+      ctu0 = tu0n;
     }
     P2_END(wave);
   } else if (role == C_::S_) {
@@ -222,11 +266,13 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1], h6U = R0[2];
     P2_BEGIN();
+    int cS = 0;   // ring position of block k
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k == -1) cprev = P::row_vertex(mh, ufirst0[tl]);   // written by U in interval -2
       if (k >= 0 && k < nb) {
-        const double* rec = &inp[k % NSLOT][0];
+        const double* rec = &inp[0][0] + cS * C_::SLOT;
+        cS = cS + 1 == NSLOT ? 0 : cS + 1;
         const double2* pw = &prep[k & 1][0][lane];
         double* zw = &zb[k & 1][0][lane];
         struct In { double2 c; double h, hh, h6; };
@@ -281,15 +327,17 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     const unsigned vx = fz ? kDropP2 : (unsigned)((size_t)b * 8) + (unsigned)csub * col8;
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1];
+    int cC = 0;   // ring position of block k-1
     P2_BEGIN();
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k >= 1 && k <= nb) {
         const int j = k - 1;
-        const double* rec = &inp[j % NSLOT][0];
-        const double* us = &ubuf[j % 4][ctl];
+        const double* rec = &inp[0][0] + cC * C_::SLOT;
+        cC = cC + 1 == NSLOT ? 0 : cC + 1;
+        const double* us = &ubuf[j & 3][ctl];
         const double* zr = &zb[j & 1][0][0];
-        const double ublk = ufirst[j % 4][ctl];
+        const double ublk = ufirst[j & 3][ctl];
         const BufP2 bx = BufP2::make(a.x + (size_t)(j * D) * colB);
 #pragma unroll
         for (int p = 0; p < C_::NPASS; ++p) {
@@ -382,12 +430,12 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
       P2_BARRIER();
       const int j = k + 1;   // read by S in interval k+1; its samples were written by U in interval k-1
       if (j < 0 || j >= nb) continue;
-      const double* us = &ubuf[j % 4][tl];
+      const double* us = &ubuf[j & 3][tl];
       double2* w = &prep[j & 1][0][lane];
 #pragma unroll
       for (int s = 0; s < D; ++s)
         w[s * 64] = double2{P::row_vertex(mh, us[(2 * s) * TPW]), P::row_vertex(mh, us[(2 * s + 1) * TPW])};
-      if (lane < TPW) ufirst[j % 4][lane] = j > 0 ? ubuf[(j - 1) % 4][(2 * D - 1) * TPW + lane] : ufirst0[lane];
+      if (lane < TPW) ufirst[j & 3][lane] = j > 0 ? ubuf[(j - 1) & 3][(2 * D - 1) * TPW + lane] : ufirst0[lane];
     }
     P2_END(wave);
   }

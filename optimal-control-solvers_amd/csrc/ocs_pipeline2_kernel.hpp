@@ -137,8 +137,11 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     // ---------------- M/P: HBM -> LDS, and the control terms of the next block for S ----------------
     const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
     (void)r; (void)b;
+    // (ring positions are carried along instead of taken as remainders: a wave's time is its instruction count)
+    int cI = 0;   // ring position of the next block to issue (blocks are issued in order)
     auto issue = [&](int j) OCS_INLINE {
-      double* dst = &inp[j % NSLOT][0];
+      double* dst = &inp[0][0] + cI * C_::SLOT;
+      cI = cI + 1 == NSLOT ? 0 : cI + 1;
 #pragma unroll
       for (int q = 0; q < C_::NREC; ++q)
         dma16_p2(a.REC + (size_t)j * C_::REC_DBL + q * 128 + 2 * lane, dst + q * 128);
@@ -148,9 +151,11 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
         dma16_p2(a.u + ((size_t)(2 * D * j + 1 + row)) * B + bw + t2, dst + C_::REC_DBL + q * 128);
       }
     };
+    int cP = NSLOT - 1;   // ring position of block j-1 of the next call of prepare (calls are in order of j)
     auto prepare = [&](int j) OCS_INLINE {   // block j has landed
       // the node before the block's first step, for the objective waves (its slot is recycled before they run)
-      if (lane < TPW) ufirst[j % 4][lane] = j > 0 ? inp[(j - 1) % NSLOT][C_::REC_DBL + (2 * D - 1) * TPW + lane] : a.u[bw + lane];
+      if (lane < TPW) ufirst[j & 3][lane] = j > 0 ? (&inp[0][0] + cP * C_::SLOT)[C_::REC_DBL + (2 * D - 1) * TPW + lane] : a.u[bw + lane];
+      cP = cP + 1 == NSLOT ? 0 : cP + 1;
     };
     P2_BEGIN();
     // Before barrier k the blocks k and k+1 have landed: P prepares block k+1 during interval k.
@@ -184,12 +189,14 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     double uprev = a.u[b];   // generic problems: the recursion evaluates F(t, y, u) itself
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1], h6U = R0[2];   // step 0's; all steps' on a uniform grid
+    int cS = 0;   // ring position of block k
     P2_BEGIN();
     for (int k = -1; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (!P::HAS_SHIFT && k >= 0 && k < nb) {
         // generic row functions (user problems given as row functions): no shifted form, no prepared terms
-        const double* rec = &inp[k % NSLOT][0];
+        const double* rec = &inp[0][0] + cS * C_::SLOT;
+        cS = cS + 1 == NSLOT ? 0 : cS + 1;
         const double* us = rec + C_::REC_DBL + tl;
         double* zw = &zb[k & 1][0][lane];
         struct Ing { double uM, uB, h, hh, h6, tA, tM, tB; };
@@ -224,7 +231,8 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
         }
       }
       if (P::HAS_SHIFT && k >= 0 && k < nb) {
-        const double* rec = &inp[k % NSLOT][0];
+        const double* rec = &inp[0][0] + cS * C_::SLOT;
+        cS = cS + 1 == NSLOT ? 0 : cS + 1;
         const double2* pw = &prep[k & 1][0][lane];
         double* zw = &zb[k & 1][0][lane];
         struct In { double2 c; double h, hh, h6; };
@@ -278,15 +286,17 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     const unsigned vx = fz ? kDropP2 : (unsigned)((size_t)b * 8) + (unsigned)csub * col8;   // node of this lane's step
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1];
+    int cC = 0;   // ring position of block k-1
     P2_BEGIN();
     for (int k = -1; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k >= 1 && k <= nb) {
         const int j = k - 1;
-        const double* rec = &inp[j % NSLOT][0];
+        const double* rec = &inp[0][0] + cC * C_::SLOT;
+        cC = cC + 1 == NSLOT ? 0 : cC + 1;
         const double* us = rec + C_::REC_DBL + ctl;
         const double* zr = &zb[j & 1][0][0];
-        const double ublk = ufirst[j % 4][ctl];
+        const double ublk = ufirst[j & 3][ctl];
         const BufP2 bx = BufP2::make(a.x + (size_t)(j * D) * colB);
 #pragma unroll
         for (int p = 0; p < C_::NPASS; ++p) {
@@ -403,9 +413,11 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
     const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
     const double mh = P::HAS_SHIFT ? P::row_shift(rp) : 0.0;
+    int cQ = 0;   // ring position of block j of the next call of prepare
     auto prepare = [&](int j) OCS_INLINE {   // block j has landed (M waits one block ahead of the barrier)
       if (!P::HAS_SHIFT) return;
-      const double* us = &inp[j % NSLOT][C_::REC_DBL] + tl;
+      const double* us = &inp[0][0] + cQ * C_::SLOT + C_::REC_DBL + tl;
+      cQ = cQ + 1 == NSLOT ? 0 : cQ + 1;
       double2* w = &prep[j & 1][0][lane];
 #pragma unroll
       for (int s = 0; s < D; ++s)
