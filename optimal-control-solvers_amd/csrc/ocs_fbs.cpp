@@ -28,7 +28,7 @@ struct ocs_fbs_state {
   int h_nact_cap = 0;
   DevBuf nact_slots;                // device: the same counters
   // work arrays
-  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid, dump;
+  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid, dump, lamlow;
 };
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
@@ -405,17 +405,20 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   HIP_TRY(hipMemsetAsync(f->usel.p, 0, sizeof(int) * B, s));
   HIP_TRY(hipMemsetAsync(status, 0, sizeof(int) * B, s));
   HIP_TRY(hipMemsetAsync(mc, 0xFF, sizeof(double) * (size_t)opt->nSWEEPS * B, s));  // all-ones = NaN
+  const ProblemDesc pd = describe(p);
+  const GridDesc gd = describe(g);
+  const FbsTables tb = tabs(g);
+  // every sweep with the control update folded into the state pass (see below): the grid samples of u are never formed
+  const bool fold = fusedup && opt->nWINDOWS <= 1 && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch) &&
+                    forward_gate_supported(pd, gd, batch) && fold_supported(pd, gd, batch);
   if (u0grid) {  // u = u0  :76
     HIP_TRY(hipMemcpyAsync(f->ugrid.p, u0grid, sizeof(double) * ugridN, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(f->uerr.p, u0err, sizeof(double) * uerrN, hipMemcpyDeviceToDevice, s));
-  } else {       // u0 = ControlBounds(:,1)*ones(1,length(t))  :23
+  } else if (!fold) {  // u0 = ControlBounds(:,1)*ones(1,length(t))  :23
     LAUNCH_TRY(launch_fill_rows(nT, nC, batch, p->d_lb.d(), f->ugrid.d(), s));
     // (with the change measured on the grid nodes the separate error-point samples are never read)
     if (!fusedup) LAUNCH_TRY(launch_fill_rows(nE, nC, batch, p->d_lb.d(), f->uerr.d(), s));
   }
-  const ProblemDesc pd = describe(p);
-  const GridDesc gd = describe(g);
-  const FbsTables tb = tabs(g);
   const int* usel = (const int*)f->usel.p;  // selects the old / new buffer of the ERROR-POINT samples only
   int nactive = batch;
   // ---- fused update, several windows of the batch on their own streams -----------------------------------------
@@ -532,14 +535,24 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     // integrates is ControlChar of the costate of the sweep before, formed inside the pass; the costate pass measures
     // the change of the control its new costate implies and takes the convergence decision.  Two kernels per sweep,
     // and the grid samples of u are neither written nor read.
-    const bool fold = opt->fused_update_off == 0 && fold_supported(pd, gd, batch);
+    // The first sweep as well: the default start u0 = lower bound (:23) is ControlChar of a costate below every
+    // switching value, so lam is set to that value (its pchip is exact, its ControlChar is the bound bit for bit) and the
+    // weighted change of sweep 1 comes out against u0 as it must.
+    if (fold) {
+      OCS_TRY(f->lamlow.ensure(sizeof(double) * nS));
+      const std::vector<double> low(nS, fold_costate_for_lower_bound());
+      HIP_TRY(hipMemcpyAsync(f->lamlow.p, low.data(), sizeof(double) * nS, hipMemcpyHostToDevice, s));
+      HIP_TRY(hipStreamSynchronize(s));   // (`low` is a local)
+      LAUNCH_TRY(launch_fill_rows(N + 1, nS, batch, f->lamlow.d(), lam, s));
+    }
     auto enqueue = [&](int sweep) -> int {
       const int* gate = sweep > 1 ? dslots + (sweep - 2) : nullptr;  // active instances after the sweep before
-      if (fold && sweep > 1) {
+      if (fold) {
         LAUNCH_TRY(launch_forward_cc(pd, gd, batch, tb.PR, p->d_lb.d(), p->d_ub.d(), x0, lam, xaug, J, status,
                                      opt->cost_row == 0, gate, s));
         LAUNCH_TRY(launch_costate_met(pd, gd, batch, xaug, nAug, tb.PR, p->d_lb.d(), p->d_ub.d(), opt->uRelTol,
-                                      opt->uAbsTol, sweep, status, mc, dslots + (sweep - 1), lam, s, gate));
+                                      opt->uAbsTol, sweep, sweep == 1 ? fold_costate_for_lower_bound() : 0.0, status, mc,
+                                      dslots + (sweep - 1), lam, s, gate));
         HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(f->wevents[sweep & 1], s));
         return OCS_OK;

@@ -14,6 +14,9 @@ bool fold_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
   return g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 && costate_forms_midpoints(p, g.N, batch) && g.TU && g.REC;
 }
 
+// LogisticK: ControlChar = clamp(sum(lam) e^{rt} / (2c), lb, ub) with c > 0 -- any hugely negative costate gives lb
+double fold_costate_for_lower_bound() { return -1.0e300; }
+
 template <class P>
 static void run_forward_cc(const FwdArgsCC& a, bool uniform, hipStream_t s) {
   using C_ = FoldCfg<P::NS>;

@@ -213,6 +213,33 @@ def test_fold_on_a_bitwise_uniform_grid(ocs, oracle, nS, N, batch):
         assert relerr(ra["u"][:, :, b], ref["u"]) < RTOL
 
 
+def test_fold_first_sweep_with_a_nonzero_lower_bound(ocs, oracle):
+    """The folded path starts from a costate whose ControlChar is the lower bound (u0 = ControlBounds(:,1), fb_sweep.m:23):
+    with lb != 0 the first sweep's weighted change, the end node included, must be taken against that bound."""
+    bounds = [[0.15, 0.6]]
+    rng = np.random.default_rng(77)
+    N, batch = 80, 64
+    tspan = oracle.linspace(0, 4, N + 1)
+    x0 = rng.uniform(0.8, 2.0, (1, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.LogisticProblem([3.0], P["c"], P["r"], bounds)
+    prob.set_batch_params([0], cs[None, :])
+    base = {"nERROR_PTS": N + 1, "nINTERP_PTS": 33, "nSWEEPS": 40}
+    ra = ocs.fb_sweep_batch(prob, x0, tspan, dict(base))
+    rd = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=3))
+    assert np.array_equal(ra["sweeps"], rd["sweeps"]) and ra["sweeps"].min() > 0
+    assert relerr(np.nan_to_num(ra["maxChange"]), np.nan_to_num(rd["maxChange"])) < 1e-6
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rd[key]) < 1e-12, key
+    for b in (0, batch - 1):
+        ref = oracle.fb_sweep(oracle.LogisticProblem([3.0], cs[b], P["r"], bounds), x0[:, b], tspan, base)
+        k = ref["_sweeps"]
+        assert ra["sweeps"][b] == k
+        assert relerr(ra["maxChange"][:k, b], ref["_maxChange"][:k]) < 1e-6
+        assert abs(ra["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
+        assert relerr(ra["u"][:, :, b], ref["u"]) < RTOL and relerr(ra["lam"][:, :, b], ref["lam"]) < RTOL
+
+
 @pytest.mark.parametrize("n,nComp,batch,nq", [(30, 3, 70, 211), (2, 1, 5, 9), (3, 2, 300, 17), (1001, 1, 64, 1001)])
 def test_batched_vector_interpolant_on_device(ocs, oracle, n, nComp, batch, nq):
     """vectorInterpolant.m:1-12 for a batch of sample sets on the device (the resampling step after the solvers,
