@@ -8,4 +8,5 @@ bash $ROOT/scripts/profile_round.sh $TAG
 NSTEPS=1000 BATCHES=4096 bash $ROOT/scripts/profile_sq.sh $TAG scripts/bench_passes.py
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/fbs_$TAG -- python3 $ROOT/scripts/fbs_prof.py > $ROOT/gpurun_out/fbs_$TAG.log 2>&1
+bash $ROOT/scripts/profile_sq.sh ${TAG}fbs scripts/fbs_prof.py    # SQ counters of the fb_sweep kernels
 echo "profile_all $TAG done"
