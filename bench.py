@@ -151,6 +151,16 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=5):
     bytes_sweep_ref = 72.0 * n_local * NSTEPS
     bytes_sweep_fold = 40.0 * n_local * NSTEPS
     bsps = float(sw.max()) / dt
+    # HBM bytes of a sweep (both kernels) from the PMC passes of scripts/profile_fbs_traffic.sh: replayed, not collected here
+    fb_traffic, fb_traffic_source = None, None
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "fb_traffic_latest.json")))
+        if n_local == 16384 and NSTEPS == 1000:
+            fb_traffic = tr["hbm_bytes_per_batch_sweep"]
+            fb_traffic_source = (f"profiles/{tr['tag']}_fb_sweep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
+                                 "k_forward_cc + k_costate_plx per live launch; replayed from that file, not collected by this run)")
+    except Exception:
+        fb_traffic = None
     return {"value": iters / dt, "unit": "fb_sweep iters/s (instance-sweeps)", "batch": batch, "n_steps": NSTEPS,
             "batch_per_gpu": hi - lo, "seconds_per_solve": dt,
             "sweeps_min": int(sw[sw > 0].min()) if (sw > 0).any() else 0,
@@ -160,7 +170,8 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=5):
                                                    "folded in (k_forward_cc) + costate pass with the convergence test "
                                                    "(k_costate_plx, MET)",
                          "achieved": bytes_sweep_fold * bsps / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": bytes_sweep_fold * bsps / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
+                         "frac": bytes_sweep_fold * bsps / 1e9 / HBM_PEAK_GBPS, "traffic": fb_traffic,
+                         "traffic_source": fb_traffic_source,
                          "algorithmic_bytes_per_batch_sweep": bytes_sweep_fold,
                          "bytes_per_instance_step": 40.0,
                          "note": "the two kernels of a sweep are marching kernels (one recursion wave per 64 instances, "
