@@ -29,6 +29,7 @@ struct ocs_fbs_state {
   DevBuf nact_slots;                // device: the same counters
   // work arrays
   DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid, dump, lamlow;
+  int lamlow_n = 0;  // number of rows lamlow holds
 };
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
@@ -539,10 +540,12 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     // switching value, so lam is set to that value (its pchip is exact, its ControlChar is the bound bit for bit) and the
     // weighted change of sweep 1 comes out against u0 as it must.
     if (fold) {
-      OCS_TRY(f->lamlow.ensure(sizeof(double) * nS));
-      const std::vector<double> low(nS, fold_costate_for_lower_bound());
-      HIP_TRY(hipMemcpyAsync(f->lamlow.p, low.data(), sizeof(double) * nS, hipMemcpyHostToDevice, s));
-      HIP_TRY(hipStreamSynchronize(s));   // (`low` is a local)
+      if (f->lamlow_n != nS) {   // (uploaded once per state size: the copy is synchronous)
+        OCS_TRY(f->lamlow.ensure(sizeof(double) * nS));
+        const std::vector<double> low(nS, fold_costate_for_lower_bound());
+        HIP_TRY(hipMemcpy(f->lamlow.p, low.data(), sizeof(double) * nS, hipMemcpyHostToDevice));
+        f->lamlow_n = nS;
+      }
       LAUNCH_TRY(launch_fill_rows(N + 1, nS, batch, f->lamlow.d(), lam, s));
     }
     auto enqueue = [&](int sweep) -> int {

@@ -6,9 +6,10 @@ ocs = g.load_package()
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(20260402)
 batch = int(os.environ.get("BATCH", "16384"))
-x0 = torch.tensor(rng.uniform(0.5, 2.5, (1, batch)), device=dev)
+x0 = torch.tensor(rng.uniform(0.5, 2.5, (int(os.environ.get("NS", "1")), batch)), device=dev)
 cs = rng.uniform(1.0, 2.0, batch)
-prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
+NS = int(os.environ.get("NS", "1"))
+prob = ocs.LogisticProblem([3.0, 2.5, 2.0, 1.5][:NS], 1.5, 0.05, [[0.0, 1.0]])
 prob.set_batch_params([0], cs[None, :])
 integ = ocs.RK4Integrator(ocs.linspace(0, 10, 1001))
 OPTS = {"fused_update_off": int(os.environ["FUO"])} if "FUO" in os.environ else None

@@ -9,7 +9,9 @@ dev = torch.device('cuda:0')
 nS, N, batch = 4, 1000, 4096
 m = [3.0, 2.5, 2.0, 1.5][:nS]
 prob = ocs.LogisticProblem(m, 1.5, 0.05, [[0.0, 1.0]])
-integ = ocs.RK4Integrator(np.linspace(0, 10, N + 1)).set_mapping(os.environ.get('MAPPING', 'auto'))
+# UNIFORM=1: steps of 2^-7 (bitwise uniform: the kernels keep the step sizes in registers); default MATLAB-style linspace
+tspan = np.arange(N + 1) / 128.0 if os.environ.get('UNIFORM') else np.linspace(0, 10, N + 1)
+integ = ocs.RK4Integrator(tspan).set_mapping(os.environ.get('MAPPING', 'auto'))
 x0 = torch.ones((nS, batch), dtype=torch.float64, device=dev)
 u = 0.05 + 0.4 * torch.rand((2 * N + 1, 1, batch), dtype=torch.float64, device=dev)
 x = torch.empty((N + 1, nS + 1, batch), dtype=torch.float64, device=dev)
