@@ -538,7 +538,8 @@ struct LQ2X {
 
 // product of this wave's row tile with a vector whose own half is known and whose other half arrives
 // through the exchange; `mid` is independent work placed behind the own half
-template <bool EXTRA, class Mid>
+// NMID: matrix instructions inside `mid` (they take part in the issue pattern below)
+template <bool EXTRA, int NMID = 0, class Mid>
 __device__ static inline LQ2Pending xmv(LQ2X& X, const double (&Fo)[4], const double (&Fx)[4], const double (&vo)[4],
                                         d4 init, double (&vx)[4], double (&f)[4], double e0, double e1, Mid&& mid) {
   const d4 z = {0.0, 0.0, 0.0, 0.0};
@@ -575,7 +576,7 @@ __device__ static inline LQ2Pending xmv(LQ2X& X, const double (&Fo)[4], const do
   // on.  A wave issues in order and blocks on a matrix instruction while the pipe is busy (~70 cycles), so
   // independent work placed BEHIND the last product would run with the pipe idle.
 #pragma unroll
-  for (int k = 0; k < 6; ++k) {
+  for (int k = 0; k < 6 + NMID; ++k) {
     __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // MFMA
     __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);  // VALU
     __builtin_amdgcn_sched_group_barrier(0x060, 2, 0);  // VMEM read / write
@@ -898,17 +899,9 @@ __global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
       uM = uact ? q.uM : 0.0;
     }
     request(i - 2, q);
-    // recompute the stage states (same products as the forward pass); only F2 and F3 need the partner's half
-    double Y2o[4], Y3o[4], Y4o[4], Yx[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Y2o[j] = __builtin_fma(cur.hh, F[j], yo[j]);
-    xmv<false>(X, P.Ao, P.Ax, Y2o, buM, Yx, F, 0.0, 0.0, nothing);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Y3o[j] = __builtin_fma(cur.hh, F[j], yo[j]);
-    xmv<false>(X, P.Ao, P.Ax, Y3o, buM, Yx, F, 0.0, 0.0, nothing);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) Y4o[j] = __builtin_fma(cur.h, F[j], yo[j]);
-
+    // k4 = h/6 lam is known when the step starts (both halves), so the matrix part of its product A'k4 runs inside
+    // the two exchanges of the recompute chain below, where the matrix pipe would wait for the partner's values;
+    // the elementwise term of :74, which needs Y4, is added when Y4 exists
     const double k4l = cur.h6 * lamc, k3l = cur.h3 * lamc, k2l = k3l, k1l = k4l;
     double k4o[4], k4x[4], k3o[4], k2o[4], k1o[4], kx[4], g3[4], g2[4], g1[4], g0[4];
 #pragma unroll
@@ -916,7 +909,32 @@ __global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
       k4o[j] = cur.h6 * lo_[j];
       k4x[j] = cur.h6 * lx_[j];
     }
-    mv2(ATo, ATx, k4o, k4x, qy(Y4o, 2.0 * cur.tcB[0] * k4l), g3);                         // :74
+    const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+    d4 g3a = z4, g3b = z4;
+    // recompute the stage states (same products as the forward pass); only F2 and F3 need the partner's half
+    double Y2o[4], Y3o[4], Y4o[4], Yx[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y2o[j] = __builtin_fma(cur.hh, F[j], yo[j]);
+    xmv<false, 4>(X, P.Ao, P.Ax, Y2o, buM, Yx, F, 0.0, 0.0, [&]() OCS_INLINE {
+      g3a = mma(ATo[0], k4o[0], g3a);
+      g3b = mma(ATo[1], k4o[1], g3b);
+      g3a = mma(ATo[2], k4o[2], g3a);
+      g3b = mma(ATo[3], k4o[3], g3b);
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y3o[j] = __builtin_fma(cur.hh, F[j], yo[j]);
+    xmv<false, 4>(X, P.Ao, P.Ax, Y3o, buM, Yx, F, 0.0, 0.0, [&]() OCS_INLINE {
+      g3a = mma(ATx[0], k4x[0], g3a);
+      g3b = mma(ATx[1], k4x[1], g3b);
+      g3a = mma(ATx[2], k4x[2], g3a);
+      g3b = mma(ATx[3], k4x[3], g3b);
+    });
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y4o[j] = __builtin_fma(cur.h, F[j], yo[j]);
+    {                                                                                     // :74
+      const d4 e = qy(Y4o, 2.0 * cur.tcB[0] * k4l), t = (g3a + g3b) + e;
+      g3[0] = t.x; g3[1] = t.y; g3[2] = t.z; g3[3] = t.w;
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) k3o[j] = __builtin_fma(cur.h, g3[j], cur.h3 * lo_[j]);    // :77
     xmv<false>(X, ATo, ATx, k3o, qy(Y3o, 2.0 * cur.tcM[0] * k3l), kx, g2, 0.0, 0.0, nothing);  // :78
