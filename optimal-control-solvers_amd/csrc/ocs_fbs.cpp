@@ -28,8 +28,7 @@ struct ocs_fbs_state {
   int h_nact_cap = 0;
   DevBuf nact_slots;                // device: the same counters
   // work arrays
-  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid, dump, lamlow;
-  int lamlow_n = 0;  // number of rows lamlow holds
+  DevBuf xaug, xmid, lam, lmid, ugrid, uerr, uint_, J, usel, status, maxchange, nactive, x0, stage, metric, anyvalid, dump;
 };
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
@@ -536,26 +535,15 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     // integrates is ControlChar of the costate of the sweep before, formed inside the pass; the costate pass measures
     // the change of the control its new costate implies and takes the convergence decision.  Two kernels per sweep,
     // and the grid samples of u are neither written nor read.
-    // The first sweep as well: the default start u0 = lower bound (:23) is ControlChar of a costate below every
-    // switching value, so lam is set to that value (its pchip is exact, its ControlChar is the bound bit for bit) and the
-    // weighted change of sweep 1 comes out against u0 as it must.
-    if (fold) {
-      if (f->lamlow_n != nS) {   // (uploaded once per state size: the copy is synchronous)
-        OCS_TRY(f->lamlow.ensure(sizeof(double) * nS));
-        const std::vector<double> low(nS, fold_costate_for_lower_bound());
-        HIP_TRY(hipMemcpy(f->lamlow.p, low.data(), sizeof(double) * nS, hipMemcpyHostToDevice));
-        f->lamlow_n = nS;
-      }
-      LAUNCH_TRY(launch_fill_rows(N + 1, nS, batch, f->lamlow.d(), lam, s));
-    }
+    // The first sweep as well: both kernels take the default start u0 = lower bound (:23) in place of ControlChar of
+    // the costate of the sweep before (which does not exist yet; what lam holds then is read and dropped).
     auto enqueue = [&](int sweep) -> int {
       const int* gate = sweep > 1 ? dslots + (sweep - 2) : nullptr;  // active instances after the sweep before
       if (fold) {
         LAUNCH_TRY(launch_forward_cc(pd, gd, batch, tb.PR, p->d_lb.d(), p->d_ub.d(), x0, lam, xaug, J, status,
-                                     opt->cost_row == 0, gate, s));
+                                     opt->cost_row == 0, gate, sweep == 1, s));
         LAUNCH_TRY(launch_costate_met(pd, gd, batch, xaug, nAug, tb.PR, p->d_lb.d(), p->d_ub.d(), opt->uRelTol,
-                                      opt->uAbsTol, sweep, sweep == 1 ? fold_costate_for_lower_bound() : 0.0, status, mc,
-                                      dslots + (sweep - 1), lam, s, gate));
+                                      opt->uAbsTol, sweep, status, mc, dslots + (sweep - 1), lam, s, gate));
         HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipEventRecord(f->wevents[sweep & 1], s));
         return OCS_OK;

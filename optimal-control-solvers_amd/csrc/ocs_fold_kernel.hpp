@@ -80,6 +80,7 @@ struct FwdArgsCC {
   const int* frozen;
   int nocost;
   const int* gate;
+  int first;            // first sweep: the control is the lower bound (u0 = ControlBounds(:,1), fb_sweep.m:23); lam is not used
 };
 
 template <class P, bool UNI>
@@ -222,12 +223,17 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         const double c3_ = (dzdxdx - dzzdx) * cih, c2_ = 2.0 * dzzdx - dzdxdx;
         lmid[r] = cw1[r] + csv * (d0[r] + csv * (c2_ + csv * c3_));
       }
-      const double uM = P::control_char_pre(ctuM, lmid, ccp, lb, ub), uB = P::control_char_pre(ctuB, cw2, ccp, lb, ub);
+      const bool u0lb = a.first != 0;   // (whatever lam holds then -- possibly NaN -- is dropped by the selects)
+      const double uMc = P::control_char_pre(ctuM, lmid, ccp, lb, ub), uBc = P::control_char_pre(ctuB, cw2, ccp, lb, ub);
+      const double uM = u0lb ? lb : uMc, uB = u0lb ? lb : uBc;
       if (vm) {
         double* us = &ubuf[jm & 3][tl];
         us[(2 * s) * TPW] = uM;
         us[(2 * s + 1) * TPW] = uB;
-        if (first) ufirst0[tl] = P::control_char_pre(ctu0, cw1, ccp, lb, ub);   // the first node of the horizon
+        if (first) {   // the first node of the horizon
+          const double u0c = P::control_char_pre(ctu0, cw1, ccp, lb, ub);
+          ufirst0[tl] = u0lb ? lb : u0c;
+        }
       }
       if (ends) {
         const int n = js * D + s + 1;

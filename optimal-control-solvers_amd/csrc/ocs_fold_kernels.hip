@@ -14,9 +14,6 @@ bool fold_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
   return g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 && costate_forms_midpoints(p, g.N, batch) && g.TU && g.REC;
 }
 
-// LogisticK: ControlChar = clamp(sum(lam) e^{rt} / (2c), lb, ub) with c > 0 -- any hugely negative costate gives lb
-double fold_costate_for_lower_bound() { return -1.0e300; }
-
 template <class P>
 static void run_forward_cc(const FwdArgsCC& a, bool uniform, hipStream_t s) {
   using C_ = FoldCfg<P::NS>;
@@ -29,9 +26,9 @@ static void run_forward_cc(const FwdArgsCC& a, bool uniform, hipStream_t s) {
 
 int launch_forward_cc(const ProblemDesc& p, const GridDesc& g, int batch, const double* PR, const double* lb,
                       const double* ub, const double* x0, const double* lam, double* x, double* J, const int* frozen,
-                      bool no_cost_row, const int* gate, hipStream_t s) {
+                      bool no_cost_row, const int* gate, bool first_sweep, hipStream_t s) {
   if (!fold_supported(p, g, batch) || !PR || !lam || !x || !J) return -1;
-  const FwdArgsCC a{g.N, batch, g.REC, PR, g.TU, p.ps, p.pb, p.pmask, lb, ub, x0, lam, x, J, frozen, no_cost_row ? 1 : 0, gate};
+  const FwdArgsCC a{g.N, batch, g.REC, PR, g.TU, p.ps, p.pb, p.pmask, lb, ub, x0, lam, x, J, frozen, no_cost_row ? 1 : 0, gate, first_sweep ? 1 : 0};
   if (p.nS == 1)
     run_forward_cc<LogisticK<1>>(a, g.uniform, s);
   else if (p.nS == 2)

@@ -183,14 +183,12 @@ bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch);
 // fb_sweep with the control update folded into the state pass (ocs_fold_kernel.hpp) and the convergence test into the
 // costate pass (k_costate_plx, MET): sweeps >= 2 are two kernels
 bool fold_supported(const ProblemDesc& p, const GridDesc& g, int batch);
-// a costate value whose ControlChar is the lower bound of the control for every problem fold_supported accepts
-double fold_costate_for_lower_bound();
 int launch_forward_cc(const ProblemDesc& p, const GridDesc& g, int batch, const double* PR, const double* lb,
                       const double* ub, const double* x0, const double* lam, double* x, double* J, const int* frozen,
-                      bool no_cost_row, const int* gate, hipStream_t s);
+                      bool no_cost_row, const int* gate, bool first_sweep, hipStream_t s);
 int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
-                       const double* lb, const double* ub, double relTol, double absTol, int sweep, double lamN_old,
-                       int* status, double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate);
+                       const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
+                       double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate);
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb = 0,
                    const double* PR = nullptr,   // xmid == NULL with PR: the kernel forms the midpoints (see below)

@@ -1023,8 +1023,7 @@ struct CostateXArgs {
   const double* lb;
   const double* ub;
   double relTol, absTol;
-  int sweep;
-  double lamN_old;     // every row of lam(t_N) on entry: 0 (compute_x_lam.m:4), or the start value of the first sweep
+  int sweep;           // sweep 1: c.lam holds nothing yet; the control before it is the lower bound (u0, fb_sweep.m:23)
   int* status;         // == c.frozen
   double* maxChange;   // [nSWEEPS][B]
   int* nactive;        // counter of the instances that continue
@@ -1169,15 +1168,13 @@ __global__ __launch_bounds__(MET ? 576 : 320) void k_costate_plx(const CostateXA
       dmax = rep ? d : dmax;
       any = any | valid;
     };
-    if (r == 0 && xw == 0) {   // node t_N: lam = 0 after the pass, lamN_old before
-      double z[G], zo[G];
+    const bool u0lb = aa.sweep == 1;   // (whatever lam held before the first sweep is dropped by the selects)
+    if (r == 0 && xw == 0) {   // node t_N: lam = 0 before and after the pass (compute_x_lam.m:4)
+      double z[G];
 #pragma unroll
-      for (int q = 0; q < G; ++q) {
-        z[q] = 0.0;
-        zo[q] = aa.lamN_old;
-      }
-      const double tuN = aa.TU[(size_t)2 * N];
-      take(P::control_char_pre(tuN, z, ccp, lb, ub), P::control_char_pre(tuN, zo, ccp, lb, ub));
+      for (int q = 0; q < G; ++q) z[q] = 0.0;
+      const double uN = P::control_char_pre(aa.TU[(size_t)2 * N], z, ccp, lb, ub);
+      take(uN, u0lb ? lb : uN);
     }
     for (int k = 0; k <= nb + 2; ++k) {
       lds_barrier();
@@ -1195,7 +1192,8 @@ __global__ __launch_bounds__(MET ? 576 : 320) void k_costate_plx(const CostateXA
           lo[qq] = slot[C_::LOFF + q * 64 + qq * TPW + tl];
         }
         const double tu = slot[C_::TUOFF + 2 * q];
-        take(P::control_char_pre(tu, ln, ccp, lb, ub), P::control_char_pre(tu, lo, ccp, lb, ub));
+        const double uo = P::control_char_pre(tu, lo, ccp, lb, ub);
+        take(P::control_char_pre(tu, ln, ccp, lb, ub), u0lb ? lb : uo);
       }
     }
 #pragma unroll
@@ -1341,11 +1339,11 @@ int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const
 
 // costate pass + change of the control + check_convergence (CostateXArgs, MET); lam holds the costate of the sweep before
 int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
-                       const double* lb, const double* ub, double relTol, double absTol, int sweep, double lamN_old,
-                       int* status, double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate) {
+                       const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
+                       double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate) {
   if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || !PR || !g.TU || !status || !maxChange || !nactive) return -1;
   const CostateXArgs a{CostateArgsPL{g.N, batch, 0, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, status, nullptr, lam},
-                       PR, gate, g.TU, lb, ub, relTol, absTol, sweep, lamN_old, status, maxChange, nactive};
+                       PR, gate, g.TU, lb, ub, relTol, absTol, sweep, status, maxChange, nactive};
   const dim3 grid(batch / (64 / p.nS)), block(576);
   if (p.nS == 1)
     k_costate_plx<LogisticK<1>, true, true><<<grid, block, 0, s>>>(a);
