@@ -140,8 +140,12 @@ static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBu
     s[j] = q[j] - tn[lo];
   }
   if (on_nodes) {
+    // "the same" up to a few units in the last place of the horizon: a tspan from another linspace than MATLAB's (numpy's
+    // differs from it in the last bit of some nodes) still has its error points on the nodes; sampling the control at
+    // the node instead of a point 1e-16 beside it changes the weighted change of :107 at round-off level only
+    const double tol = 8.0 * 2.220446049250313e-16 * std::max(std::fabs(tn[0]), std::fabs(tn[n - 1]));
     bool same = nq == n;
-    for (int j = 0; same && j < n; ++j) same = q[j] == tn[j];
+    for (int j = 0; same && j < n; ++j) same = std::fabs(q[j] - tn[j]) <= tol;
     *on_nodes = same;
   }
   OCS_TRY(upload(K, k.data(), sizeof(int) * nq));

@@ -18,7 +18,7 @@ for case in range(ncases):
     T = float(rng.uniform(0.5, 6.0))
     kind = rng.integers(0, 3) if case % 4 == 3 else rng.integers(0, 2)   # (an irregular grid takes the unfolded path)
     if kind == 0:
-        tspan = ocs.linspace(0, T, N + 1)   # MATLAB's linspace: the error points (fb_sweep.m:69) then are the nodes, bit for bit
+        tspan = ocs.linspace(0, T, N + 1) if case % 3 else np.linspace(0, T, N + 1)   # MATLAB-style or numpy linspace
     elif kind == 1:
         tspan = np.arange(N + 1) * 2.0 ** -5
     else:
