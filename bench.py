@@ -260,6 +260,39 @@ def bl2_large_batch_metric(ocs, dev, batch=65536, reps=5):
                          "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None}}
 
 
+def bl2_single_state_metric(ocs, dev, batch=4096, reps=50):
+    """"reduces to TestOCProblem when nS = 1 -- also benchmark that nAug = 2 case": the same grid,
+    batch and candidates with one state (96 B per trajectory-step), automatic mapping (k_forward_p2 + k_backward_scan)."""
+    tspan, _, u_h = make_inputs(batch, dev, 20260401)
+    prob = ocs.TestOCProblem({"c": C_PAR, "m": 3.0, "r": R_PAR}, [[0.0, 1.0]])
+    integ = ocs.RK4Integrator(tspan)
+    x0, u = torch.ones((1, batch), dtype=torch.float64, device=dev), torch.tensor(u_h, device=dev)
+    x = torch.empty((NSTEPS + 1, 2, batch), dtype=torch.float64, device=dev)
+    lam, dJdu = torch.empty_like(x), torch.empty_like(u)
+    J = torch.empty(batch, dtype=torch.float64, device=dev)
+
+    def pair():
+        integ.compute_states_dev(prob, x0, u, x, J)
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+    for _ in range(20):
+        pair()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pair()
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / reps
+    nbytes = 8.0 * (3 * 2 + 6 * 1) * batch * NSTEPS
+    return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "nS": 1,
+            "ms_per_pass_pair": dt * 1e3,
+            "roofline": {"bound": "hbm (at 64 workgroups on 256 CUs the passes are bound by their serial chains: a quarter "
+                                  "of the chip is in use)",
+                         "kernel": "k_forward_p2 + k_backward_scan, pass pair", "achieved": nbytes / dt / 1e9,
+                         "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS,
+                         "traffic": None, "traffic_source": None},
+            "finite": bool(torch.isfinite(J).all().item())}
+
+
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (= fp64 vector peak), public spec
 
 
@@ -495,12 +528,15 @@ def main():
         b4 = bl4_metric(ocs, dev)
         b5 = bl5_metric(ocs, dev)
         big = bl2_large_batch_metric(ocs, dev) if world == 1 else None
+        one = bl2_single_state_metric(ocs, dev) if world == 1 else None
         if rank == 0:
             line["fb_sweep"] = fb
             line["other_configs"] = {"BL-4 chebyshev16 objective+gradient": b4,
                                      "BL-5 LQ32 + RK4InfiniteIntegrator (matrix cores)": b5}
             if big:
                 line["other_configs"]["BL-2 problem at batch 65536 (lane mapping, HBM-bound regime)"] = big
+            if one:
+                line["other_configs"]["BL-2 shapes with one state (TestOCProblem, nAug = 2)"] = one
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             cb, ref = cpu_baseline(tspan, x0_h, u_h)
