@@ -264,6 +264,10 @@ typedef struct ocs_fbs_options {
                            one window under the streaming kernels of another); results do not depend on it */
   int cost_row;         /* default 0: the running-objective row of xaug (row nS) is left unspecified -- soln of the
                            reference holds x, lam, u and the scalar J only (fb_sweep.m:117-125); 1 writes it */
+  double uRelax;        /* extension, default 0 = off: the reference has no damping (u = uNew, :85) and its sweep may
+                           oscillate or diverge (-> empty struct, :77).  0 < uRelax < 1 replaces :85 by
+                           u = u + uRelax (uNew - u), on the grid and at the error points, after the unchanged test of
+                           :107-110; the solution returned on convergence is that of the reference's final_sweep(u) */
 } ocs_fbs_options;
 int ocs_fbs_default_options(ocs_fbs_options *o);
 /* [x, lam(, J)] = compute_x_lam(_J)(prob, x0, tspan, u, RelTol, AbsTol)   compute_x_lam.m:1-19, compute_x_lam_J.m:1-21

@@ -5,7 +5,8 @@
 function soln = gpu_fb_sweep(prob, x0, tspan, options)                         % fb_sweep.m:1
    integ = GpuRK4Integrator(tspan);  o = libstruct('ocs_fbs_options');
    calllib('libocs', 'ocs_fbs_default_options', o);                           % :16-22
-   names = {'uRelTol', 'uAbsTol', 'nSWEEPS', 'nERROR_PTS', 'nINTERP_PTS'};              % :26-59
+   names = {'uRelTol', 'uAbsTol', 'nSWEEPS', 'nERROR_PTS', 'nINTERP_PTS', ...          % :26-59
+            'uRelax'};       % extension: damped update u = u + uRelax (uNew - u); 0 = the reference's u = uNew (:85)
    if nargin > 3
       for k = 1:numel(names)
          if isfield(options, names{k}), o.(names{k}) = options.(names{k}); end

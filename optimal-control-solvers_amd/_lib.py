@@ -107,7 +107,7 @@ class FbsOptions(C.Structure):
     """struct ocs_fbs_options (include/ocs.h)."""
     _fields_ = [("uRelTol", C.c_double), ("uAbsTol", C.c_double), ("nSWEEPS", C.c_int),
                 ("nERROR_PTS", C.c_int), ("nINTERP_PTS", C.c_int), ("fused_update_off", C.c_int), ("nWINDOWS", C.c_int),
-                ("cost_row", C.c_int)]
+                ("cost_row", C.c_int), ("uRelax", C.c_double)]
 
 
 class SsOptions(C.Structure):

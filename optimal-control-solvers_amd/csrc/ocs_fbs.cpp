@@ -230,6 +230,7 @@ int ocs_fbs_default_options(ocs_fbs_options* o) {
   o->fused_update_off = 0;
   o->nWINDOWS = 0;
   o->cost_row = 0;
+  o->uRelax = 0.0;
   return OCS_OK;
 }
 
@@ -395,6 +396,9 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // Error points on the grid nodes and the default start: the control at the error points is the node samples of the
   // grid control, so the weighted change is taken while the grid control is replaced (one kernel, one pass over x and
   // lam) instead of in a separate error-point kernel with its own copy of the control.
+  // damped update (extension, ocs.h): u = u + om (uNew - u); om = 1 is the reference's u = uNew
+  if (opt->uRelax < 0.0 || opt->uRelax > 1.0) return fail(OCS_ERR_INVALID, "uRelax must be in [0, 1]");
+  const double om = opt->uRelax > 0.0 ? opt->uRelax : 1.0;
   const int fuo = opt->fused_update_off == 3 ? 0 : opt->fused_update_off;   // 3: as 0, without the fold below
   const bool fusedup = f->err_on_nodes && !u0grid && fuo != 1;
   const int nparts = fusedup ? control_grid_parts(N) : control_pts_parts(nE);
@@ -413,7 +417,8 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const GridDesc gd = describe(g);
   const FbsTables tb = tabs(g);
   // every sweep with the control update folded into the state pass (see below): the grid samples of u are never formed
-  const bool fold = fusedup && opt->nWINDOWS <= 1 && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch) &&
+  // (not with a damped update: that needs the samples of the control it damps)
+  const bool fold = fusedup && om == 1.0 && opt->nWINDOWS <= 1 && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch) &&
                     forward_gate_supported(pd, gd, batch) && fold_supported(pd, gd, batch);
   if (u0grid) {  // u = u0  :76
     HIP_TRY(hipMemcpyAsync(f->ugrid.p, u0grid, sizeof(double) * ugridN, hipMemcpyDeviceToDevice, s));
@@ -481,7 +486,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       LAUNCH_TRY(launch_costate(pj, gd, cnt, xaug + off, nAug, f->xmid.d() + off, f->ugrid.d() + off, status + off,
                                 f->dump.d() + off, lam + off, st, batch));
       LAUNCH_TRY(launch_control_grid(pj, gd, tb, cnt, xaug + off, nAug, f->xmid.d() + off, lam + off, f->ugrid.d() + off,
-                                     status + off, f->metric.d() + off, opt->uRelTol, opt->uAbsTol, st, batch));
+                                     status + off, f->metric.d() + off, opt->uRelTol, opt->uAbsTol, st, batch, nullptr, om));
       int* slot = dslots + (size_t)j * nsw + (sweep - 1);
       LAUNCH_TRY(launch_fbs_advance(cnt, sweep, nparts, f->metric.d() + off, (int*)f->anyvalid.p + off,
                                     (int*)f->usel.p + off, status + off, mc + off, slot, st, batch));
@@ -561,7 +566,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, nullptr, f->ugrid.d(), status, f->dump.d(), lam, s, 0, tb.PR,
                                 gate));
       LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, nullptr, lam, f->ugrid.d(), status, f->metric.d(),
-                                     opt->uRelTol, opt->uAbsTol, s, 0, gate));
+                                     opt->uRelTol, opt->uAbsTol, s, 0, gate, om));
       LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
                                     mc, dslots + (sweep - 1), s, 0, gate));
       HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
@@ -597,7 +602,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       // x, lam, J are the ones computed above from the old control, which is what final_sweep(u) returns (:82).
       LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, xmid, f->ugrid.d(), status, f->dump.d(), lam, s, 0, tb.PR));
       LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, xmid, lam, f->ugrid.d(), status, f->metric.d(),
-                                     opt->uRelTol, opt->uAbsTol, s));
+                                     opt->uRelTol, opt->uAbsTol, s, 0, nullptr, om));
       LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
                                     mc, (int*)f->nactive.p, s));
       HIP_TRY(hipMemcpyAsync(&nactive, f->nactive.p, sizeof(int), hipMemcpyDeviceToHost, s));
@@ -609,14 +614,14 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     // (:81, :99-115) folded in
     LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
                                   f->uerr.d(), usel, (long long)uerrN, f->metric.d(),
-                                  (int*)f->anyvalid.p, opt->uRelTol, opt->uAbsTol, s));
+                                  (int*)f->anyvalid.p, opt->uRelTol, opt->uAbsTol, s, om));
     LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p,
                                   (int*)f->usel.p, status, mc, (int*)f->nactive.p, s));
     // u = uNew (:85) on the integrator grid, only for the instances that continue: a converged instance
     // keeps its OLD control, which is what final_sweep(u) integrates (:82)
     // (lam's pchip midpoints are formed inside the kernel)
     LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, f->xmid.d(), lam, f->ugrid.d(), status, nullptr, 0.0, 0.0,
-                                   s));
+                                   s, 0, nullptr, om));
     HIP_TRY(hipMemcpyAsync(&nactive, f->nactive.p, sizeof(int), hipMemcpyDeviceToHost, s));
     HIP_TRY(hipStreamSynchronize(s));
   }

@@ -367,6 +367,7 @@ struct ControlGridArgs {
   double relTol, absTol;
   int ld;  // row distance when the launch covers a window of a larger batch; 0 = batch
   const int* gate;  // optional: the launch does nothing if *gate == 0
+  double relax;     // the samples become u + relax (uNew - u) (1: the reference's u = uNew, fb_sweep.m:85)
 };
 
 template <class P>
@@ -417,6 +418,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
           any = true;
         }
       }
+      if (a.relax != 1.0) u[c] = __builtin_fma(a.relax, u[c] - *dst, *dst);   // damped update (extension)
       OCS_FBS_USTORE(u[c], dst);
     }
   };
@@ -511,6 +513,7 @@ struct ControlPtsArgs {
   double* metric;  // [blocks in y][B]: this block's maximum for instance b, or -1 if none of its values was valid
   int* anyvalid;   // unused (kept for the argument layout)
   double relTol, absTol;
+  double relax;    // error-point mode: the samples become u + relax (uNew - u) (1: the reference's u = uNew, fb_sweep.m:85)
 };
 
 constexpr int kPtsPerThread = 8;
@@ -587,6 +590,7 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
         wmax = any ? fmax(wmax, w) : w;
         any = true;
       }
+      if (a.relax != 1.0) u[c] = __builtin_fma(a.relax, u[c] - o, o);   // damped update (extension; after the test)
     }
   }
 #pragma unroll

@@ -75,9 +75,9 @@ static void run_control_grid(const ControlGridArgs& a, hipStream_t s) {
 int control_grid_parts(int N) { return (N + kPchipRun - 1) / kPchipRun; }
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
-                        double relTol, double absTol, hipStream_t s, int ldb, const int* gate) {
+                        double relTol, double absTol, hipStream_t s, int ldb, const int* gate, double relax) {
   const ControlGridArgs a{g.N, batch, g.TU, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, xmid, lam, make_tab(t), t.TM, u,
-                          status, metric, relTol, absTol, ldb, gate};
+                          status, metric, relTol, absTol, ldb, gate, relax};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, (g.N + kPchipRun - 1) / kPchipRun), dim3(256), args, s);
@@ -94,9 +94,9 @@ static void run_control_pts(const ControlPtsArgs& a, hipStream_t s) {
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
                        const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
-                       double absTol, hipStream_t s) {
+                       double absTol, hipStream_t s, double relax) {
   const ControlPtsArgs a{nq, batch, make_tab(t), KQ, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out,
-                         usel, odelta, metric, anyvalid, relTol, absTol};
+                         usel, odelta, metric, anyvalid, relTol, absTol, relax};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_CONTROL_PTS, dim3((batch + 255) / 256, (nq + kPtsPerThread - 1) / kPtsPerThread),

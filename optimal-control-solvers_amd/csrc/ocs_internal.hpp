@@ -215,11 +215,12 @@ int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* 
                   const double* V, double* out, hipStream_t s);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
-                        double relTol, double absTol, hipStream_t s, int ldb = 0, const int* gate = nullptr);
+                        double relTol, double absTol, hipStream_t s, int ldb = 0, const int* gate = nullptr,
+                        double relax = 1.0);
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
                        const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
-                       double absTol, hipStream_t s);
+                       double absTol, hipStream_t s, double relax = 1.0);
 int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
 int control_pts_parts(int nq);  // rows of the partial-maximum array `metric` [parts][B] that launch_control_pts fills
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,

@@ -28,7 +28,8 @@ def _options(options):
     o = FbsOptions()
     check(lib.ocs_fbs_default_options(C.byref(o)))
     options = dict(options or {})
-    for k in ("uRelTol", "uAbsTol", "nSWEEPS", "nERROR_PTS", "nINTERP_PTS", "fused_update_off", "nWINDOWS", "cost_row"):
+    for k in ("uRelTol", "uAbsTol", "nSWEEPS", "nERROR_PTS", "nINTERP_PTS", "fused_update_off", "nWINDOWS", "cost_row",
+              "uRelax"):
         if k in options:
             setattr(o, k, options[k])
     # RelTol / AbsTol (fb_sweep.m:18-19) steer odevr7's adaptive step control.  Here the passes are classical RK4 on

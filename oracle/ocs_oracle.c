@@ -789,6 +789,7 @@ void ocs_or_fbs_default_options(ocs_or_fbs_options *o) {
   o->nSWEEPS = 50;      /* :20 */
   o->nERROR_PTS = 1001; /* :21 */
   o->nINTERP_PTS = 1001; /* :22 */
+  o->uRelax = 0.0;
 }
 
 /* compute_x_lam.m:1-19 / compute_x_lam_J.m:1-21 with odevr7 -> grid RK4.
@@ -909,8 +910,13 @@ int ocs_or_fb_sweep(const ocs_or_rk4 *g, const ocs_or_problem *p, const double *
       converged_at = sweepIdx;
       break;
     }
-    memcpy(u, uNew, sizeof(double) * (size_t)nC * nT); /* u = uNew :85 */
-    memcpy(uErr, uErrNew, sizeof(double) * (size_t)nC * o->nERROR_PTS);
+    if (o->uRelax > 0.0 && o->uRelax < 1.0) { /* damped update (extension): u = u + w (uNew - u) */
+      for (size_t i = 0; i < (size_t)nC * nT; ++i) u[i] = fma(o->uRelax, uNew[i] - u[i], u[i]);
+      for (size_t i = 0; i < (size_t)nC * o->nERROR_PTS; ++i) uErr[i] = fma(o->uRelax, uErrNew[i] - uErr[i], uErr[i]);
+    } else {
+      memcpy(u, uNew, sizeof(double) * (size_t)nC * nT); /* u = uNew :85 */
+      memcpy(uErr, uErrNew, sizeof(double) * (size_t)nC * o->nERROR_PTS);
+    }
   }
   free(errorPts);
   free(interpPts);

@@ -132,6 +132,7 @@ typedef struct {
   int nSWEEPS;             /* :20 */
   int nERROR_PTS;          /* :21 */
   int nINTERP_PTS;         /* :22 */
+  double uRelax;           /* extension (include/ocs.h): 0 = off; 0 < uRelax < 1: u = u + uRelax (uNew - u) instead of :85 */
 } ocs_or_fbs_options;
 void ocs_or_fbs_default_options(ocs_or_fbs_options *o);
 /* ugrid: nC x (2N+1) samples of u on the grid.  x: nS x (N+1), lam: nS x (N+1), J optional */

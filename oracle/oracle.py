@@ -115,7 +115,7 @@ def lib():
 
 class FbsOptions(C.Structure):
     _fields_ = [("uRelTol", C.c_double), ("uAbsTol", C.c_double), ("nSWEEPS", C.c_int),
-                ("nERROR_PTS", C.c_int), ("nINTERP_PTS", C.c_int)]
+                ("nERROR_PTS", C.c_int), ("nINTERP_PTS", C.c_int), ("uRelax", C.c_double)]
 
 
 def linspace(a, b, n):
@@ -430,7 +430,7 @@ def fb_sweep(prob, x0, tspan, options=None):
     N = integ.nSTEPS
     o = FbsOptions()
     lib().ocs_or_fbs_default_options(C.byref(o))
-    for k in ("uRelTol", "uAbsTol", "nSWEEPS", "nERROR_PTS", "nINTERP_PTS"):
+    for k in ("uRelTol", "uAbsTol", "nSWEEPS", "nERROR_PTS", "nINTERP_PTS", "uRelax"):
         if k in options:
             setattr(o, k, options[k])
     T0, TF = integ.t[0], integ.t[-1]

@@ -313,3 +313,37 @@ def test_sweeps_enqueued_ahead_equal_the_plain_loop(ocs, nSWEEPS):
         assert relerr(a, b) < 1e-12, key
     ma, mb = ra["maxChange"].cpu().numpy(), rb["maxChange"].cpu().numpy()
     assert np.array_equal(np.isnan(ma), np.isnan(mb)) and relerr(np.nan_to_num(ma), np.nan_to_num(mb)) < 1e-6
+
+
+def test_damped_update_extension(ocs, oracle):
+    """The reference has no damping (u = uNew, fb_sweep.m:85).  uRelax (an extension, off by default) replaces :85 by
+    u = u + uRelax (uNew - u) after the unchanged convergence test.  On TestOCProblem the undamped sweep is already a
+    contraction, so damping only slows it down; what is checked is the rule itself: instance by instance the oracle's
+    loop with the same rule (sweep counts, change history, solution), the same results from every mapping of the update
+    (fused with the change of the control / separate kernels), the same fixed point as the undamped sweep."""
+    rng = np.random.default_rng(5)
+    N, batch = 96, 64
+    tspan = oracle.linspace(0, 3.0, N + 1)
+    x0 = rng.uniform(0.8, 1.6, (1, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.LogisticProblem([3.0], P["c"], P["r"], BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    base = {"nERROR_PTS": N + 1, "nINTERP_PTS": 33, "nSWEEPS": 120}
+    plain = ocs.fb_sweep_batch(prob, x0, tspan, dict(base))
+    damped = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, uRelax=0.6))
+    assert plain["sweeps"].min() > 0 and damped["sweeps"].min() > 0
+    assert np.all(damped["sweeps"] > plain["sweeps"])
+    assert relerr(damped["J"], plain["J"]) < 1e-6 and relerr(damped["u"], plain["u"]) < 1e-5      # the same fixed point
+    sep = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, uRelax=0.6, fused_update_off=1))
+    assert np.array_equal(damped["sweeps"], sep["sweeps"])
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(damped[key], sep[key]) < 1e-12, key
+    for b in (0, batch // 2, batch - 1):
+        ref = oracle.fb_sweep(oracle.LogisticProblem([3.0], cs[b], P["r"], BOUNDS), x0[:, b], tspan, dict(base, uRelax=0.6))
+        k = ref["_sweeps"]
+        assert damped["sweeps"][b] == k > 0
+        assert relerr(damped["maxChange"][:k, b], ref["_maxChange"][:k]) < 1e-6
+        assert abs(damped["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
+        assert relerr(damped["u"][:, :, b], ref["u"]) < RTOL and relerr(damped["lam"][:, :, b], ref["lam"]) < RTOL
+    with pytest.raises(Exception):
+        ocs.fb_sweep_batch(prob, x0, tspan, dict(base, uRelax=1.5))
