@@ -214,7 +214,7 @@ void ocs_or_adjointRHS(const ocs_or_problem *p, int k, const double *t, const do
                        const double *lam, const double *u, double *out) {
   const int nS = p->nS, nAug = p->nAug;
   double *y = (double *)calloc((size_t)nAug * k, sizeof(double));
-  double *v = (double *)malloc(sizeof(double) * (size_t)nAug * k);
+  double *v = (double *)calloc((size_t)nAug * k, sizeof(double));
   double *g = (double *)malloc(sizeof(double) * (size_t)nAug * k);
   for (int j = 0; j < k; ++j) {
     memcpy(y + (size_t)j * nAug, x + (size_t)j * nS, sizeof(double) * nS);
