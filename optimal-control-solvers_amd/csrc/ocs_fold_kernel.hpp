@@ -56,11 +56,6 @@ struct FoldCfg {
          : G == 2 ? (w == 0 ? M_ : w == 1 ? S_ : w == 5 ? P_ : w == 9 ? J_ : (w == 2 || w == 3 || w == 4 || w == 6) ? C_ : U_)
                   : (w == 0 ? M_ : w == 1 ? S_ : w == 5 ? P_ : w == 4 ? J_ : (w == 2 || w == 3) ? C_ : U_);
   }
-  __device__ static constexpr int index_in_role(int w) {   // how many waves below w have w's role
-    int n = 0;
-    for (int v = 0; v < w; ++v) n += role(v) == role(w);
-    return n;
-  }
 };
 
 struct FwdArgsCC {
@@ -174,10 +169,6 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     for (int k = C_::KHEAD; k <= nb + 1; ++k) {
       P2_BARRIER();
       const int js = k + 3, jm = k + 2;
-#if defined(OCS_FOLD_ABL) && OCS_FOLD_ABL == 1
-      if (jm >= 0 && jm < nb) { ubuf[jm & 3][tl + (2 * s) * TPW] = 0.3; ubuf[jm & 3][tl + (2 * s + 1) * TPW] = 0.3; ufirst0[tl] = 0.3; }
-      continue;
-#endif
       const bool vs = js < nb, vm = (unsigned)jm < (unsigned)nb;
       // ---- slopes: node n = js D + s + 1, the right node of this lane's step of block js ----
       const double* slotS = &inp[0][0] + c3 * C_::SLOT;
