@@ -1080,7 +1080,7 @@ __device__ static inline void costate_midpoints(const double (*inp)[C_::SLOT], d
     double d[RL + 1];  // slopes at nodes iLo+q0 .. iLo+q0+RL
 #pragma unroll
     for (int c = 0; c < RL + 1; ++c) {
-      d[c] = pchip_interior1(sec[c], sec[c + 1], c < RL ? pr[c][6] : pr[RL - 1][8], c < RL ? pr[c][7] : pr[RL - 1][9]);
+      d[c] = pchip_interior_f(sec[c], sec[c + 1], c < RL ? pr[c][6] : pr[RL - 1][8], c < RL ? pr[c][7] : pr[RL - 1][9]);
     }
     if (iLo + q0 == 0) d[0] = pchip_end_pl(pr[0][1], pr[0][2], sec[1], sec[2]);
     if (iLo + q0 + RL == N) d[RL] = pchip_end_pl(pr[RL - 1][1], pr[RL - 1][0], sec[RL], sec[RL - 1]);
