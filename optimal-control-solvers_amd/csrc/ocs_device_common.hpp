@@ -102,7 +102,10 @@ __device__ static inline double pchip_interior_f(double del0, double del1, doubl
 }
 
 // per-interval pchip records of the node grid (built by k_pchip_records, streamed by k_costate_plx / k_forward_cc):
-// doubles per interval i: {h(i-1), h(i), h(i+1), 1/h(i-1), 1/h(i), 1/h(i+1), W1(i), W2(i), W1(i+1), W2(i+1), tmid_i - t_i, pad}
+// doubles per interval i: {h(i-1), h(i), h(i+1), 1/h(i-1), 1/h(i), 1/h(i+1), W1(i), W2(i), W1(i+1), W2(i+1), tmid_i - t_i, h(i)/8, pad}
+// pchip at the MIDDLE of an interval (all the sweep kernels need) is the Hermite cubic's closed form there,
+// (y0 + y1)/2 + h/8 (d0 - d1): four operations instead of the ten of the general evaluation; tmid_i is the rounded
+// (t_i + t_i+1)/2, so this differs from evaluating at tmid_i by round-off
 constexpr int kPRec = 16;
 // pchip end slope (MATLAB pchipslopes' three-point formula with its two shape-preserving corrections)
 __device__ static inline double pchip_end_pl(double h0, double h1, double del0, double del1) {

@@ -86,7 +86,7 @@ static int ensure_tables(ocs_integrator_s* g) {
   std::vector<double> ih(N);
   for (int i = 0; i < N; ++i) ih[i] = 1.0 / h[i];
   OCS_TRY(upload(f->IH, ih.data(), sizeof(double) * N));
-  {  // per-interval records: {h(i-1),h(i),h(i+1), their reciprocals, W1(i),W2(i),W1(i+1),W2(i+1), tmid-t(i), pad}
+  {  // per-interval records: {h(i-1),h(i),h(i+1), their reciprocals, W1(i),W2(i),W1(i+1),W2(i+1), tmid-t(i), h(i)/8, pad}
     const int R = costate_prec();
     std::vector<double> pr((size_t)N * R, 0.0);
     auto cl = [&](int k) { return k < 0 ? 0 : (k > N - 1 ? N - 1 : k); };
@@ -101,6 +101,7 @@ static int ensure_tables(ocs_integrator_s* g) {
       q[8] = w1[i + 1];
       q[9] = w2[i + 1];
       q[10] = tm[i] - tn[i];
+      q[11] = 0.125 * h[i];   // the Hermite cubic at the middle of its interval: (y0 + y1)/2 + h/8 (d0 - d1)
     }
     OCS_TRY(upload(f->PR, pr.data(), sizeof(double) * pr.size()));
   }

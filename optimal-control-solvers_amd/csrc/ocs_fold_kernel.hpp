@@ -162,7 +162,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     static_assert(C_::KHEAD == -3, "ring positions at the first interval");
     const uniform_ptr PRu = as_uniform(a.PR), TUu = as_uniform(a.TU);
     double cw1[G], cw2[G], cd1[G];          // carried: nodes i, i+1 and the slope at i+1 of the step whose samples come next
-    double cih = 0.0, csv = 0.0, ctuM = 0.0, ctuB = 0.0, ctu0 = 0.0;
+    double csv = 0.0, ctuM = 0.0, ctuB = 0.0, ctu0 = 0.0;   // csv: h/8 of that step
 #pragma unroll
     for (int r = 0; r < G; ++r) cw1[r] = cw2[r] = cd1[r] = 0.0;
     P2_BEGIN();
@@ -180,12 +180,12 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
       if constexpr (G == 1) {
         const int i = vs ? js * D + s : 0;                  // (wave-uniform)
         const uniform_ptr q = PRu + (size_t)i * kPRec;
-        ih0 = q[4]; ih1 = q[5]; W1 = q[8]; W2 = q[9]; svn = q[10];
+        ih0 = q[4]; ih1 = q[5]; W1 = q[8]; W2 = q[9]; svn = q[11];
         tu0n = TUu[2 * i]; tuMn = TUu[2 * i + 1]; tuBn = TUu[2 * i + 2];
         if (ends) { hE0 = q[0]; hE1 = q[1]; hE2 = q[2]; ihE = q[3]; }
       } else {
         const double* prS = slotS + C_::POFF + s * kPRec;   // record of interval n-1
-        ih0 = prS[4]; ih1 = prS[5]; W1 = prS[8]; W2 = prS[9]; svn = prS[10];
+        ih0 = prS[4]; ih1 = prS[5]; W1 = prS[8]; W2 = prS[9]; svn = prS[11];
         tu0n = slotS[C_::TOFF + 2 * s]; tuMn = slotS[C_::TOFF + 2 * s + 1]; tuBn = slotS[C_::TOFF + 2 * s + 2];
         if (ends) { hE0 = prS[0]; hE1 = prS[1]; hE2 = prS[2]; ihE = prS[3]; }
       }
@@ -209,10 +209,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
       for (int r = 0; r < G; ++r) {
         const double sa = (wb[r] - wa[r]) * ih0, sb = (wc[r] - wb[r]) * ih1;
         dn[r] = pchip_interior_f(sa, sb, W1, W2);
-        const double sec1 = (cw2[r] - cw1[r]) * cih;
-        const double dzzdx = (sec1 - d0[r]) * cih, dzdxdx = (cd1[r] - sec1) * cih;
-        const double c3_ = (dzdxdx - dzzdx) * cih, c2_ = 2.0 * dzzdx - dzdxdx;
-        lmid[r] = cw1[r] + csv * (d0[r] + csv * (c2_ + csv * c3_));
+        lmid[r] = __builtin_fma(csv, d0[r] - cd1[r], 0.5 * (cw1[r] + cw2[r]));   // the cubic at the middle of its interval
       }
       const bool u0lb = a.first != 0;   // (whatever lam holds then -- possibly NaN -- is dropped by the selects)
       const double uMc = P::control_char_pre(ctuM, lmid, ccp, lb, ub), uBc = P::control_char_pre(ctuB, cw2, ccp, lb, ub);
@@ -245,7 +242,6 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         cw2[r] = wb[r];
         cd1[r] = dn[r];
       }
-      cih = ih0;
       csv = svn;
       ctuM = tuMn;
       ctuB = tuBn;

@@ -1055,11 +1055,11 @@ __device__ static inline void costate_midpoints(const double (*inp)[C_::SLOT], d
     // Straight-line on purpose (no branch between the LDS reads, all slopes as interior ones behind an opaque
     // barrier): the three divisions then overlap; written with branches this wave took longer than the recursion.
     // records of the run
-    double pr[RL][11];
+    double pr[RL][12];
 #pragma unroll
     for (int c = 0; c < RL; ++c)
 #pragma unroll
-      for (int e = 0; e < 11; ++e) pr[c][e] = slot[POFF + (q0 + c) * kPRec + e];
+      for (int e = 0; e < 12; ++e) pr[c][e] = slot[POFF + (q0 + c) * kPRec + e];
     // nodes iLo+q0-1 .. iLo+q0+RL+1 of this lane's row (ascending): own block, one node of the block below
     // (j+1), two of the block above (j-1) or x(t_N); a node outside the grid reads some valid address instead
     double w[RL + 3];
@@ -1086,12 +1086,8 @@ __device__ static inline void costate_midpoints(const double (*inp)[C_::SLOT], d
     if (iLo + q0 + RL == N) d[RL] = pchip_end_pl(pr[RL - 1][1], pr[RL - 1][0], sec[RL], sec[RL - 1]);
     double* out = &xm[j & 1][0][lane];
 #pragma unroll
-    for (int c = 0; c < RL; ++c) {
-      const double ih0 = pr[c][4], sv = pr[c][10], sb = sec[c + 1];
-      const double dzzdx = (sb - d[c]) * ih0, dzdxdx = (d[c + 1] - sb) * ih0;
-      const double c3 = (dzdxdx - dzzdx) * ih0, c2 = 2.0 * dzzdx - dzdxdx;
-      out[(q0 + c) * 64] = w[c + 1] + sv * (d[c] + sv * (c2 + sv * c3));
-    }
+    for (int c = 0; c < RL; ++c)   // the cubic at the middle of its interval (ocs_device_common.hpp, kPRec)
+      out[(q0 + c) * 64] = __builtin_fma(pr[c][11], d[c] - d[c + 1], 0.5 * (w[c + 1] + w[c + 2]));
   }
 }
 
