@@ -88,9 +88,10 @@ __device__ static inline double pchip_interior_s(double del0, double del1, doubl
 
 // ... and with the quotient by reciprocal + Newton steps instead of the IEEE division sequence (no scaling: the secants of
 // a costate are far from the ends of the exponent range; at most an ulp from the correctly rounded quotient)
+// (v_rcp_f64 is good to 2^29 ulp, i.e. ~1e-7 relative; one Newton step on the reciprocal takes that to ~1e-14, and the
+//  correction of the quotient multiplies the two errors: full precision in six operations)
 __device__ static inline double fast_div(double n, double d) {
   double r = __builtin_amdgcn_rcp(d);
-  r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
   r = __builtin_fma(__builtin_fma(-d, r, 1.0), r, r);
   const double q = n * r;
   return __builtin_fma(__builtin_fma(-d, q, n), r, q);
