@@ -3,7 +3,7 @@
 # calibration factors are those of the same round's profile_round.sh run (profiles/<TAG>_traffic.json).
 #   bash scripts/profile_fbs_traffic.sh TAG   then: python scripts/summarize_fbs_traffic.py TAG
 set -o pipefail
-TAG=${1:-r02c}
+TAG=${1:-r02d}
 ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/fbstraffic_$TAG
 mkdir -p $OUT
