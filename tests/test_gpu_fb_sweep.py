@@ -347,3 +347,27 @@ def test_damped_update_extension(ocs, oracle):
         assert relerr(damped["u"][:, :, b], ref["u"]) < RTOL and relerr(damped["lam"][:, :, b], ref["lam"]) < RTOL
     with pytest.raises(Exception):
         ocs.fb_sweep_batch(prob, x0, tspan, dict(base, uRelax=1.5))
+
+
+def test_numpy_linspace_grid_takes_the_same_path(ocs, oracle):
+    """fb_sweep.m:69 builds the error points with MATLAB's linspace; numpy's differs from it in the last bit of some nodes.
+    Error points within a few ulp of the nodes count as the nodes (so such a tspan does not fall back to the unfused
+    kernels); the results agree with those on the MATLAB-style grid to round-off and with the oracle on the same grid."""
+    rng = np.random.default_rng(9)
+    N, batch = 200, 64
+    ta, tb = oracle.linspace(0, 10, N + 1), np.linspace(0, 10, N + 1)
+    assert not np.array_equal(ta, tb)          # the premise: the two grids differ in some last bits
+    x0 = rng.uniform(0.5, 2.5, (1, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    opts = {"nERROR_PTS": N + 1, "nINTERP_PTS": 41}
+    ra = ocs.fb_sweep_batch(prob, x0, ta, opts)
+    rb = ocs.fb_sweep_batch(prob, x0, tb, opts)
+    assert np.array_equal(ra["sweeps"], rb["sweeps"]) and ra["sweeps"].min() > 0
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rb[key]) < 1e-11, key
+    for b in (0, batch - 1):
+        ref = oracle.fb_sweep(oracle.TestOCProblem({"c": cs[b], "m": P["m"], "r": P["r"]}, BOUNDS), x0[:, b], tb, opts)
+        assert rb["sweeps"][b] == ref["_sweeps"]
+        assert abs(rb["J"][b] - ref["J"]) < RTOL * abs(ref["J"]) and relerr(rb["lam"][:, :, b], ref["lam"]) < RTOL
