@@ -543,7 +543,8 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   if (aligned) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      pchip_run<kPtsPerThread>(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0, sq, xw[k]);
+      // (a ControlChar that does not read x -- P::CC_READS_X -- leaves the state out: half the traffic of this kernel)
+      if (P::CC_READS_X) pchip_run<kPtsPerThread>(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0, sq, xw[k]);
       pchip_run<kPtsPerThread>(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0, sq, lw[k]);
     }
   }
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   if (aligned) {
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      x[k] = xw[k][cq];
+      x[k] = P::CC_READS_X ? xw[k][cq] : 0.0;
       lam[k] = lw[k][cq];
     }
   } else {
@@ -564,7 +565,7 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
     const double s = a.SQ[q];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      x[k] = pchip_eval(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, k0, s);
+      x[k] = P::CC_READS_X ? pchip_eval(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, k0, s) : 0.0;
       lam[k] = pchip_eval(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, k0, s);
     }
   }

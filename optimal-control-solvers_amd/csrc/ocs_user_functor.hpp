@@ -68,6 +68,7 @@ __device__ static inline void ocs_dFdu_times_vec(double t, const double* y, cons
 namespace ocs {
 
 struct UserP {
+  static constexpr bool CC_READS_X = true;   // unknown: ocs_ControlChar may read x
   static constexpr int NS = OCS_USER_NS;
   static constexpr int NC = OCS_USER_NC;
   static constexpr int NAUG = OCS_USER_NS + 1;
