@@ -1,4 +1,5 @@
-// ocs_fold_kernel.hpp -- state pass of sweep k >= 2 of the forward-backward sweep with the control update folded in.
+// ocs_fold_kernel.hpp -- state pass of the forward-backward sweep with the control update folded in (sweep 1: a flag puts
+// the default start u0 = lower bound in the place of ControlChar of a costate that does not exist yet).
 //
 // fb_sweep.m:79-87 alternates  [x, lam] = compute_x_lam(u)  and  u = ControlChar(t, x(t), lam(t))  on the grid.  For the
 // problems of the wave-specialised kernels ControlChar does not read x, so the control a state pass integrates is a
@@ -7,8 +8,9 @@
 // them back was the largest kernel of a sweep (k_control_grid: 24 B per instance and step written, 8 + 8 read);
 // here the state pass reads the costate rows instead (8 B) and forms its control samples on the way:
 //
-//   wave M    streams the step records, the pchip interval records, the ControlChar time coefficients and the node rows
-//             of lam of a block of D = 8 steps HBM -> LDS (LDS-DMA), Q blocks ahead;
+//   wave M    streams the step records and the node rows of lam of a block of D = 8 steps HBM -> LDS (LDS-DMA), Q blocks
+//             ahead; for nS > 1 also the pchip interval records and the ControlChar time coefficients (at nS = 1 a
+//             control wave's step is the same for all lanes and it reads those with scalar loads);
 //   waves U   (D / G of them) take one step of a block each, lane (step, trajectory), in two stages one interval apart:
 //             the pchip slope at the step's right node (block k+3; each slope is formed once and handed on through
 //             LDS), then lam at the half step from the two slopes, ControlChar at the half step and at the right
@@ -19,8 +21,9 @@
 //   M: issues block k+5+Q, waits for block k+5     U: slopes of block k+3, samples of block k+2     P: block k+1
 //   S: block k     C: block k-1     J: block k-2
 // A block's slot is read from interval j-4 (the slopes of block j-1 take its first two nodes) to j+1 (C): NSLOT = Q + 7.
-// The arithmetic of S, C and J is k_forward_p2's; the control samples agree with k_control_grid's to round-off (the
-// same pchip formulas, the interval records of k_costate_plx instead of the node tables).
+// The arithmetic of S, C and J is k_forward_p2's; the control samples agree with k_control_grid's to round-off (pchip
+// slopes by reciprocal + Newton step, the cubic at the middle of an interval in closed form, 1/(2c) of ControlChar
+// hoisted: ocs_device_common.hpp, LogisticK::control_char_pre).
 #pragma once
 #include "ocs_pipeline2_kernel.hpp"
 
