@@ -8,6 +8,7 @@
 #include <dlfcn.h>
 
 #include "ocs_jit.hpp"
+#include <cstdlib>
 
 #include "_obj/ocs_jit_sources.inc"  // generated: the kernel headers as string literals
 
@@ -127,8 +128,14 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   const std::vector<std::string> names = kernel_names(nS, rowsep);
   for (const std::string& n : names)
     if (!n.empty()) r->AddNameExpression(prog, n.c_str());
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast"};
-  const hiprtcResult rc = r->CompileProgram(prog, 4, opts);
+  // The include directory of the ROCm installation explicitly: hipRTC normally serves <hip/hip_runtime.h> from a built-in
+  // copy, but not in every process environment (under rocprofv3 started from another directory the compilation failed
+  // with "'hip/hip_runtime.h' file not found").
+  const char* rocm = getenv("ROCM_PATH");
+  if (!rocm || !*rocm) rocm = getenv("HIP_PATH");
+  const std::string inc = std::string("-I") + ((rocm && *rocm) ? rocm : "/opt/rocm") + "/include";
+  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc.c_str()};
+  const hiprtcResult rc = r->CompileProgram(prog, 5, opts);
   size_t logsz = 0;
   r->GetProgramLogSize(prog, &logsz);
   if (logsz > 1) {
