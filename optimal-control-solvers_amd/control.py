@@ -99,8 +99,9 @@ class Control:
 
 def _set_fusion(self, mode):
     """Where the basis is dense with <= 32 functions, nlp_objective can apply it inside the RK4 kernels:
-    "auto" (large batches), "off", "on" (whenever supported)."""
-    check(lib.ocs_control_set_fusion(self._h, {"auto": 0, "off": 1, "on": 2}[mode]))
+    "auto" (large batches), "off", "on" (whenever supported), "lane" (as "on", but on the lane-per-trajectory kernels
+    even where the wave-specialised ones with the basis products on the matrix cores apply)."""
+    check(lib.ocs_control_set_fusion(self._h, {"auto": 0, "off": 1, "on": 2, "lane": 3}[mode]))
     return self
 
 

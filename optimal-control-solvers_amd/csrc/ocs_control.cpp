@@ -17,7 +17,8 @@ struct ocs_control_s {
   DevBuf d_colptr, d_row, d_cval, d_rowptr, d_col, d_rval, d_BT, d_BT16, d_CT;
   bool banded = false;  // every column has at most two consecutive non-zeros and the band moves up by at most one row
   int band_r0 = 0;      // per column (PWLinear, PWConstant): column table d_CT for the fused banded kernels
-  int fuse_mode = 0;  // ocs_control_set_fusion: 0 automatic, 1 never, 2 whenever the fused kernels support the case
+  int fuse_mode = 0;  // ocs_control_set_fusion: 0 automatic, 1 never, 2 whenever the fused kernels support the case,
+                      // 3 as 2 but on the lane kernels (k_forward_fc / k_backward_fc) only
   bool dense = false;  // more than half of B is non-zero and nBasis <= 32: register-resident dense kernels
   bool uploaded = false;
   hipStream_t stream = nullptr;
@@ -472,7 +473,11 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   // N = 1000 (ms per evaluation, unfused / fused): batch 64 0.80 / 0.43, 4096 0.90 / 0.44, 65536 2.54 / 0.61,
   // 262144 6.28 / 2.02.  With 3-4 states and a small batch the wave-specialised unfused passes are kept.
   const bool fusable = c->dense && g->kind == 0 && fused_control_supported(p->functor, p->nS, p->nC, c->nBasis);
-  const bool fused = fusable && c->fuse_mode != 1 && (c->fuse_mode == 2 || p->nS <= 2 || batch >= 8192);
+  const bool fused = fusable && c->fuse_mode != 1 && (c->fuse_mode >= 2 || p->nS <= 2 || batch >= 8192);
+  // ... and where the shapes allow it (one state row, whole blocks and tiles) on the wave-specialised state pass and the
+  // adjoint scan with the basis products on the matrix cores (ocs_fused_wave_kernels.hip)
+  const bool fusedw = fused && c->fuse_mode != 3 &&
+                      fused_wave_supported(p->functor, p->nS, p->nC, c->nBasis, g->N, batch);
   // Banded basis (PWLinear, PWConstant): the same with two live coefficient rows per trajectory
   // (ocs_fused_banded_kernels.hip)
   // Measured (TestOCProblem, N = 500, PWLinear 101 points; ms per evaluation unfused / fused): batch 4096 0.16 / 0.31,
@@ -517,6 +522,15 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
     OCS_TRY(bind_problem(g, p, batch, s));
     OCS_TRY(g->d_ck.ensure(sizeof(double) * (size_t)nAug * (g->N + 1) * B));
     g->ck = nullptr;  // these checkpoints belong to no u in memory: a later compute_adjoints must not use them
+    if (fusedw && describe(g).RECS) {
+      const int ldbt = c->nBasis <= 16 ? 16 : 32;
+      LAUNCH_TRY(launch_forward_fcw(describe(p), describe(g), batch, c->nBasis, ldbt, c->d_BT16.d(), v, x0, g->d_ck.d(), J, s));
+      LAUNCH_TRY(launch_backward_fcs(describe(p), describe(g), batch, c->nBasis, ldbt, c->d_BT16.d(), v, g->d_ck.d(), dJdv,
+                                     lam0, s));
+      if (nFree > 0)
+        LAUNCH_TRY(launch_gather_rows(nFree, batch, (const int*)c->d_idx.p, lam0, dJdv + (size_t)nV * B, s));
+      return OCS_OK;
+    }
     LAUNCH_TRY(launch_forward_fc(describe(p), describe(g), batch, c->nBasis, c->d_BT16.d(), v, x0, g->d_ck.d(), J, s));
     LAUNCH_TRY(launch_backward_fc(describe(p), describe(g), batch, c->nBasis, c->d_BT16.d(), v, g->d_ck.d(), dJdv,
                                   lam0, s));
@@ -537,7 +551,8 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
 
 int ocs_control_set_fusion(ocs_control c, int mode) {
   if (!c) return fail(OCS_ERR_INVALID, "null control");
-  if (mode < 0 || mode > 2) return fail(OCS_ERR_INVALID, "fusion mode must be 0 (automatic), 1 (off) or 2 (on)");
+  if (mode < 0 || mode > 3)
+    return fail(OCS_ERR_INVALID, "fusion mode must be 0 (automatic), 1 (off), 2 (on) or 3 (on, lane kernels only)");
   c->fuse_mode = mode;
   return OCS_OK;
 }

@@ -156,6 +156,14 @@ int launch_forward_fc(const ProblemDesc& p, const GridDesc& g, int batch, int nB
 int launch_backward_fc(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, const double* BT16,
                        const double* v, const double* ck, double* dJdv, double* lam0, hipStream_t s);
 
+// the same on the wave-specialised state pass and the adjoint scan, both basis products on the matrix cores
+// (ocs_fused_wave_kernels.hip); BT: [2N+1][ldbt] as BT16
+bool fused_wave_supported(Functor f, int nS, int nC, int nBasis, int N, int batch);
+int launch_forward_fcw(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, int ldbt, const double* BT,
+                       const double* v, const double* x0, double* ck, double* J, hipStream_t s);
+int launch_backward_fcs(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, int ldbt, const double* BT,
+                        const double* v, const double* ck, double* dJdv, double* lam0, hipStream_t s);
+
 // the same for a banded basis (PWLinear, PWConstant; ocs_fused_banded_kernels.hip).  CT: column table
 // [2N+1][fused_banded_rec()] = {w0, w1, adv, pad}, r0 the first row of column 0; dJdv must be zero-filled
 bool fused_banded_supported(Functor f, int nS, int nC);

@@ -82,8 +82,8 @@ static std::vector<std::string> kernel_names(int nS, bool rowsep) {
   n[UK_TU_AT] = "ocs::k_tu_at<ocs::UserP>";
   n[UK_EQUILIBRIUM] = "ocs::k_equilibrium<ocs::UserP>";
   if (rowsep) {   // (entries left empty are not compiled)
-    n[UK_FWD_P2_X] = "ocs::k_forward_p2<ocs::UserP, true, true, false>";
-    n[UK_FWD_P2_J] = "ocs::k_forward_p2<ocs::UserP, false, true, false>";
+    n[UK_FWD_P2_X] = "ocs::k_forward_p2<ocs::UserP, true, true, false, 0>";
+    n[UK_FWD_P2_J] = "ocs::k_forward_p2<ocs::UserP, false, true, false, 0>";
     n[UK_SCAN_LAM_DJDU] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, true, false, 0>";
     n[UK_SCAN_LAM] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, false, false, 0>";
     n[UK_SCAN_DJDU] = "ocs::k_backward_scan<ocs::UserP, 16, 4, false, true, false, 0>";

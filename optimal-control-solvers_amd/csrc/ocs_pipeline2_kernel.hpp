@@ -76,24 +76,44 @@ struct BufP2 {
   }
 };
 
-template <int G>
+// NKS > 0: the control samples are not read from memory but expanded in the kernel from the coefficients of a dense
+// basis, u(:, j) = sum_k v_k B(k, j) (Control/ChebyshevControl.m:35-38), by NUW waves on the matrix cores: NKS k-steps of
+// v_mfma_f64_16x16x4_f64 per tile of 16 samples x 16 trajectories (role U below).  Only the step records are streamed then.
+template <int G, int NKS = 0>
 struct P2Cfg {
   static constexpr int D = 8;                        // steps per block
   static constexpr int TPW = 64 / G;                 // trajectories per workgroup
-  static constexpr int Q = (G == 1) ? 6 : 8;         // blocks the DMA runs ahead of the preparation (an interval is
-                                                     // ~0.3 us: HBM latency needs several; vmcnt counts to 63)
+  static constexpr int Q = NKS > 0 ? 2 : (G == 1) ? 6 : 8;   // blocks the DMA runs ahead of the preparation (an interval is
+                                                     // ~0.3 us: HBM latency needs several; vmcnt counts to 63; the record
+                                                     // table alone is shared by all workgroups and sits in L2)
   static constexpr int NSLOT = Q + 3;                // input ring (block j: prepared in interval j-1, read by C in j+1)
   static constexpr int RS = rec_stride(1), SCO = rec_sc_offset(1);
   static constexpr int REC_DBL = D * RS, NREC = REC_DBL / 128;
   static constexpr int U_DBL = 2 * D * TPW, NU = U_DBL / 128;
   static constexpr int SLOT = REC_DBL + U_DBL;
-  static constexpr int LPB = NREC + NU;
+  static constexpr int LPB = NREC + (NKS > 0 ? 0 : NU);
   static constexpr int NCW = (G == 4) ? 2 : 4;       // objective/store waves
   static constexpr int SPW = D / NCW;                // steps per such wave and block
   static constexpr int NPASS = SPW / G > 0 ? SPW / G : 1;
-  static constexpr int NWAVE = 4 + NCW;              // M, S, C.., J, P
+  static constexpr int NT = TPW / 16;                // tiles of 16 trajectories (NKS > 0)
+  static constexpr int NUW = NKS > 0 ? (G == 1 ? 2 : 1) : 0;   // expansion waves
+  static constexpr int TW = NKS > 0 ? NT / NUW : 0;  // tiles per expansion wave
+  static constexpr int NWAVE = 4 + NCW + NUW;        // M, S, C.., J, P (, U..)
   static_assert(REC_DBL % 128 == 0 && U_DBL % 128 == 0 && (SPW % G == 0 || G > SPW), "block shapes");
+  static_assert(NKS == 0 || (2 * D == 16 && NT >= 1 && NKS <= 8), "a block of samples is one 16-row tile");
+  // role of a wave (0 M, 1 S, 2.. C, 2 + NCW J, 3 + NCW P, 4 + NCW.. U).  A workgroup's waves are dealt to the four
+  // SIMDs in turn (wave w and w + 4 share one): with the expansion waves present the recursion wave gets the SIMD of
+  // the nearly idle M wave, the matrix work goes beside the objective waves.
+  __device__ static constexpr int role(int w) {
+    if (NKS == 0) return w;
+    constexpr int M_ = 0, S_ = 1, C_ = 2, J_ = 2 + NCW, P_ = 3 + NCW, U_ = 4 + NCW;
+    if (G == 1) { constexpr int r[10] = {U_, U_ + 1, S_, J_, C_, C_ + 1, M_, P_, C_ + 2, C_ + 3}; return r[w]; }
+    if (G == 2) { constexpr int r[9] = {U_, C_, S_, C_ + 2, J_, C_ + 1, M_, C_ + 3, P_}; return r[w]; }
+    constexpr int r[7] = {U_, C_, S_, C_ + 1, J_, P_, M_};
+    return r[w];
+  }
 };
+typedef double d4_p2 __attribute__((ext_vector_type(4)));
 
 struct FwdArgsP2 {
   int N, batch;
@@ -109,14 +129,18 @@ struct FwdArgsP2 {
   int ld;              // row distance of the arrays (window of a larger batch) or 0
   int nocost;          // leave the running-objective row of x unwritten (J only)
   const int* gate;     // optional: the launch does nothing if *gate == 0
+  // NKS > 0 (u expanded in the kernel; `u` is not read):
+  const double* BT = nullptr;   // [2N+1][ldbt]: transposed basis, zero-padded to 4 NKS functions
+  const double* v = nullptr;    // [nBasis][B] coefficients (one control)
+  int nBasis = 0, ldbt = 0;
 };
 
 // UNI: uniform grid -- the step sizes are the same for every step and stay in registers
-template <class P, bool OUT_X, bool FRZ, bool UNI>
-__global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const FwdArgsP2 a) {
+template <class P, bool OUT_X, bool FRZ, bool UNI, int NKS = 0>
+__global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(const FwdArgsP2 a) {
   constexpr int G = P::NS, NAUG = P::NAUG;
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels: one control, one time coefficient");
-  using C_ = P2Cfg<G>;
+  using C_ = P2Cfg<G, NKS>;
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
   constexpr int NCW = C_::NCW, SPW = C_::SPW;
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];   // {records | u}
@@ -124,7 +148,7 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
   __shared__ double ufirst[4][TPW];
   __shared__ __attribute__((aligned(16))) double2 prep[2][D][64];        // (cM, cB) of a step, per S lane (wave P -> S)                                       // control sample at the first node of a block
   __shared__ double dd[2][D][TPW];                                        // objective increments of a block
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int wave = C_::role(__builtin_amdgcn_readfirstlane(threadIdx.x >> 6));
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int nb = a.N / D;
@@ -146,13 +170,14 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
       for (int q = 0; q < C_::NREC; ++q)
         dma16_p2(a.REC + (size_t)j * C_::REC_DBL + q * 128 + 2 * lane, dst + q * 128);
 #pragma unroll
-      for (int q = 0; q < C_::NU; ++q) {
+      for (int q = 0; q < C_::NU && NKS == 0; ++q) {
         const int e = q * 128 + 2 * lane, row = e / TPW, t2 = e % TPW;
         dma16_p2(a.u + ((size_t)(2 * D * j + 1 + row)) * B + bw + t2, dst + C_::REC_DBL + q * 128);
       }
     };
     int cP = NSLOT - 1;   // ring position of block j-1 of the next call of prepare (calls are in order of j)
     auto prepare = [&](int j) OCS_INLINE {   // block j has landed
+      if (NKS > 0) return;   // (the expansion waves do this)
       // the node before the block's first step, for the objective waves (its slot is recycled before they run)
       if (lane < TPW) ufirst[j & 3][lane] = j > 0 ? (&inp[0][0] + cP * C_::SLOT)[C_::REC_DBL + (2 * D - 1) * TPW + lane] : a.u[bw + lane];
       cP = cP + 1 == NSLOT ? 0 : cP + 1;
@@ -185,14 +210,18 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     const bool fz = FRZ && a.frozen != nullptr && a.frozen[b] != 0;
     const double mh = P::HAS_SHIFT ? P::row_shift(rp) : 0.0;
     double z = a.x0[(size_t)r * B + b] - mh;
-    double cprev = P::HAS_SHIFT ? P::row_vertex(mh, a.u[b]) : 0.0;
-    double uprev = a.u[b];   // generic problems: the recursion evaluates F(t, y, u) itself
+    double uprev = NKS > 0 ? 0.0 : a.u[b];   // generic problems: the recursion evaluates F(t, y, u) itself
+    double cprev = P::HAS_SHIFT ? P::row_vertex(mh, uprev) : 0.0;
     const uniform_ptr R0 = as_uniform(a.REC);
     const double hU = R0[0], hhU = R0[1], h6U = R0[2];   // step 0's; all steps' on a uniform grid
     int cS = 0;   // ring position of block k
     P2_BEGIN();
     for (int k = -1; k <= nb + 1; ++k) {
       P2_BARRIER();
+      if (NKS > 0 && k == -1) {   // the first sample, from the expansion waves
+        uprev = ufirst[0][tl];
+        cprev = P::HAS_SHIFT ? P::row_vertex(mh, uprev) : 0.0;
+      }
       if (!P::HAS_SHIFT && k >= 0 && k < nb) {
         // generic row functions (user problems given as row functions): no shifted form, no prepared terms
         const double* rec = &inp[0][0] + cS * C_::SLOT;
@@ -406,7 +435,7 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     }
     P2_END(wave);
     if (!fz && sg == 0) a.J[b] = carry;
-  } else {
+  } else if (wave == 3 + NCW) {
     // ---------------- P: the control terms of the next block for S ----------------
     // P::row_vertex(m_r/2, u) = m_r^2/4 - u for the two new samples of every step, per S lane: two instructions less
     // on the recursion wave, which is bound by its instruction count
@@ -430,6 +459,69 @@ __global__ __launch_bounds__(P2Cfg<P::NS>::NWAVE * 64) void k_forward_p2(const F
     for (int k = -1; k <= nb + 1; ++k) {
       P2_BARRIER();
       if (k + 1 < nb) prepare(k + 1);   // read by S in interval k+1; prep[(k+1)&1] was last read in interval k-1
+    }
+    P2_END(wave);
+  } else if constexpr (NKS > 0) {
+    // ---------------- U: the control samples of block k+2 from the coefficients ----------------
+    // One block = 16 samples (2 D): the tile D[i][n] = sum_k A[i][k] B[k][n] with A[i][k] = B(k, sample 16 j + 1 + i)
+    // (wave-uniform data: lane (g, i) = (lane >> 4, lane & 15) holds the entry of k-slot g), B[k][n] = v_k of
+    // trajectory n (lane (g, n) holds k-slot g: constant for the whole kernel).  Lane (g, n) ends up with rows 4 m + g
+    // of column n in register m and writes them where the samples landed when they came from memory.
+    constexpr int TW = C_::TW;
+    const int uw = wave - (4 + NCW);
+    const int g = lane >> 4, n = lane & 15;
+    double vB[TW][NKS];
+#pragma unroll
+    for (int tq = 0; tq < TW; ++tq)
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) {
+        const int kk = 4 * ks + g;
+        const double val = a.v[(size_t)(kk < a.nBasis ? kk : 0) * B + bw + 16 * (uw * TW + tq) + n];
+        vB[tq][ks] = kk < a.nBasis ? val : 0.0;
+      }
+    const int nT = 2 * a.N + 1;
+    double aA[NKS];
+    auto load_a = [&](int j) OCS_INLINE {   // rows of block j, clamped to the grid (block -1: sample 0 in every row)
+      int smp = 2 * D * j + 1 + n;
+      smp = smp < 0 ? 0 : (smp >= nT ? nT - 1 : smp);
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks) aA[ks] = a.BT[(size_t)smp * a.ldbt + 4 * ks + g];
+    };
+    double ulast[TW];   // lanes g == 3: the last sample of the block before (the node before a block's first step)
+    int cU = 0;
+    auto compute = [&](int j) OCS_INLINE {   // a's rows are those of block j
+      double* dst = &inp[0][0] + cU * C_::SLOT + C_::REC_DBL;
+      d4_p2 acc[TW];
+#pragma unroll
+      for (int tq = 0; tq < TW; ++tq) acc[tq] = d4_p2{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < NKS; ++ks)
+#pragma unroll
+        for (int tq = 0; tq < TW; ++tq) acc[tq] = __builtin_amdgcn_mfma_f64_16x16x4f64(aA[ks], vB[tq][ks], acc[tq], 0, 0, 0);
+      load_a(j + 1);
+      if (j >= 0) {
+        cU = cU + 1 == NSLOT ? 0 : cU + 1;
+#pragma unroll
+        for (int tq = 0; tq < TW; ++tq) {
+          const int t2 = 16 * (uw * TW + tq) + n;
+          if (g == 3) ufirst[j & 3][t2] = ulast[tq];
+          dst[(0 + g) * TPW + t2] = acc[tq].x;
+          dst[(4 + g) * TPW + t2] = acc[tq].y;
+          dst[(8 + g) * TPW + t2] = acc[tq].z;
+          dst[(12 + g) * TPW + t2] = acc[tq].w;
+        }
+      }
+#pragma unroll
+      for (int tq = 0; tq < TW; ++tq) ulast[tq] = acc[tq].w;
+    };
+    P2_BEGIN();
+    load_a(-1);
+    compute(-1);
+    compute(0);
+    if (nb > 1) compute(1);
+    for (int k = -1; k <= nb + 1; ++k) {
+      P2_BARRIER();
+      if (k >= 0 && k + 2 < nb) compute(k + 2);   // its slot last held block k-1-Q, read by C long ago
     }
     P2_END(wave);
   }

@@ -376,6 +376,49 @@ def test_fused_control_objective_gradient(ocs, oracle, nS, nB, N, batch):
     cg.set_fusion("auto")
 
 
+@pytest.mark.parametrize("nB,N,batch,grid", [(16, 1000, 128, "lin"), (5, 8, 64, "lin"), (32, 64, 192, "rand"), (20, 200, 64, "lin"),
+                                             (1, 72, 64, "lin"), (13, 136, 320, "rand"), (4, 1000, 64, "np")])
+def test_fused_control_wave_kernels(ocs, oracle, nB, N, batch, grid):
+    """single_shooting.m:137-150 + ChebyshevControl.m:35-43 on the wave-specialised state pass and the adjoint scan with
+    u = v B and dJdv = dJdu B' on the matrix cores (csrc/ocs_fused_wave_kernels.hip): against the oracle's unfused
+    composition, the lane-per-trajectory fused kernels and the unfused path.  Shapes: one to three superblocks of the scan
+    with dead chunks (N = 8, 72, 136), 1..32 basis functions (one to eight k-steps, two gradient tiles), several
+    workgroups, a non-uniform grid, a numpy linspace (not bitwise uniform), a free initial state, a per-trajectory
+    parameter."""
+    rng = np.random.default_rng(nB * 1000 + N)
+    T = 10.0 if N >= 50 else 1.0
+    tspan = {"lin": oracle.linspace(0, T, N + 1), "np": np.linspace(0, T, N + 1),
+             "rand": np.concatenate([[0.0], np.sort(rng.uniform(0, T, N - 1)), [T]])}[grid]
+    g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    cg, co = ocs.ChebyshevControl(g.t, nB, 1), oracle.ChebyshevControl(go.t, nB, 1)
+    V = 0.05 * rng.normal(size=(nB, batch)) / np.arange(1, nB + 1)[:, None]
+    V[0] += 0.4
+    V = np.vstack([V, rng.uniform(0.8, 1.6, (1, batch))])
+    cs = rng.uniform(1.0, 2.0, batch)
+    x0 = rng.uniform(0.8, 1.5, (1, batch))
+    pg = ocs.LogisticProblem([3.0], P["c"], P["r"], BOUNDS)
+    pg.set_batch_params([0], cs[None, :])
+    out = {}
+    for mode in ("on", "lane", "off"):
+        cg.set_fusion(mode)
+        out[mode] = ocs.nlp_objective(g, pg, cg, x0.copy(), V, FreeInitStates=[1])
+    Jw, dw, x0w = out["on"]
+    for other in ("lane", "off"):
+        Jl, dl, x0l = out[other]
+        assert relerr(Jw, Jl) < 1e-13 and relerr(dw, dl) < RTOL and np.array_equal(x0w, x0l), other
+    for b in sorted({0, 15, 16, batch // 2 + 1, batch - 1}):
+        po = oracle.LogisticProblem([3.0], cs[b], P["r"], BOUNDS)
+        Jo, do, _ = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b], FreeInitStates=[1])
+        assert abs(Jw[b] - Jo) < RTOL * max(1.0, abs(Jo)) and relerr(dw[:, b], do) < RTOL
+    # without free initial states (no lam0 output)
+    cg.set_fusion("on")
+    J2, d2, _ = ocs.nlp_objective(g, pg, cg, x0.copy(), V[:nB])
+    cg.set_fusion("lane")
+    J3, d3, _ = ocs.nlp_objective(g, pg, cg, x0.copy(), V[:nB])
+    assert relerr(J2, J3) < 1e-13 and relerr(d2, d3) < RTOL
+    cg.set_fusion("auto")
+
+
 @pytest.mark.parametrize("kind,nS,nB,N,batch", [("lin", 1, 101, 500, 70), ("lin", 1, 2, 7, 3), ("lin", 2, 11, 50, 130),
                                                 ("lin", 4, 33, 64, 64), ("lin", 1, 51, 50, 5), ("lin", 3, 300, 40, 9),
                                                 ("const", 1, 50, 500, 70), ("const", 2, 1, 9, 65), ("const", 4, 7, 50, 33),
