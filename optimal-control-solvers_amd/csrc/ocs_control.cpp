@@ -18,7 +18,8 @@ struct ocs_control_s {
   bool banded = false;  // every column has at most two consecutive non-zeros and the band moves up by at most one row
   int band_r0 = 0;      // per column (PWLinear, PWConstant): column table d_CT for the fused banded kernels
   int fuse_mode = 0;  // ocs_control_set_fusion: 0 automatic, 1 never, 2 whenever the fused kernels support the case,
-                      // 3 as 2 but on the lane kernels (k_forward_fc / k_backward_fc) only
+                      // (the wave-specialised ones where they apply, at any batch), 3 as 2 but on the lane kernels
+                      // (k_forward_fc / k_backward_fc) only
   bool dense = false;  // more than half of B is non-zero and nBasis <= 32: register-resident dense kernels
   bool uploaded = false;
   hipStream_t stream = nullptr;
@@ -476,7 +477,7 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   const bool fused = fusable && c->fuse_mode != 1 && (c->fuse_mode >= 2 || p->nS <= 2 || batch >= 8192);
   // ... and where the shapes allow it (one state row, whole blocks and tiles) on the wave-specialised state pass and the
   // adjoint scan with the basis products on the matrix cores (ocs_fused_wave_kernels.hip)
-  const bool fusedw = fused && c->fuse_mode != 3 &&
+  const bool fusedw = fused && c->fuse_mode != 3 && (c->fuse_mode == 2 || batch <= 32768) &&
                       fused_wave_supported(p->functor, p->nS, p->nC, c->nBasis, g->N, batch);
   // Banded basis (PWLinear, PWConstant): the same with two live coefficient rows per trajectory
   // (ocs_fused_banded_kernels.hip)

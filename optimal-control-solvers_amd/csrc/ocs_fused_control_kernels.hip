@@ -17,6 +17,13 @@
 // samples used to be), and `v_fmac_f64_dpp ... row_newbcast:k` multiplies by lane k's value of the own
 // 16-lane row, i.e. by B(k,j) -- gfx950's only DPP mode for fp64, exactly a broadcast.  No scalar loads
 // (they return out of order and would need ~100 SGPRs for the rows in flight), no LDS.
+//
+// Tried in round 3 and dropped: the two products with the basis matrix as v_mfma_f64_16x16x4_f64 tiles in this lane mapping
+// (tiles transposed through wave-private LDS, the matrix instructions spread between the steps).  On gfx950 the fp64 matrix
+// instruction occupies the SIMD's fp64 datapath for its 64 cycles -- it does not run beside fp64 vector instructions, of
+// the same wave or of another (scripts/probe/mfma_valu_overlap.hip: 1 MFMA + 16 FMAs take 188-200 cycles, 64 + 104 apart)
+// -- so the 1024 multiply-adds of a tile cost what sixteen v_fmac_f64_dpp cost, plus the transposition: 486 us against
+// 426 us per evaluation at batch 64, 667 against 604 us at batch 65 536.
 #include "ocs_device_common.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_problems.hpp"

@@ -28,6 +28,8 @@
 #include "ocs_pipeline2_kernel.hpp"
 #include "ocs_problems.hpp"
 #include "ocs_scan_kernel.hpp"
+#include <cstdio>
+#include <cstdlib>
 
 namespace ocs {
 
@@ -52,6 +54,21 @@ __device__ static inline void swap32_fw(double a, double& lower, double& upper) 
   upper = __hiloint2double((int)hi[1], (int)lo[1]);
 }
 
+// 16-byte-per-lane LDS-DMA as dma16_sc, issued from inline assembly.  The compiler orders every later LDS read behind the
+// LDS-DMA instructions it knows about once there are more than a few of them in flight (a vmcnt(0) right behind their
+// issue: the whole memory latency, every superblock); the kernel below waits for its DMAs itself, one superblock later.
+__device__ static inline void dma16_fw(const double* src, const double* lds_dst) {
+  const unsigned m0v = (unsigned)(unsigned long long)(const __attribute__((address_space(3))) void*)lds_dst;
+  asm volatile("s_mov_b32 m0, %1\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(src), "s"(m0v) : "memory", "m0");
+}
+
+#ifdef OCS_FCS_STAMPS
+__device__ static long long g_fcs_stamp[8 * 8];   // workgroup 0: per wave, cycles per segment of a superblock, summed
+#define FCS_T(k) do { const long long t_ = __builtin_amdgcn_s_memtime(); seg_[k] += t_ - tl_; tl_ = t_; } while (0)
+#else
+#define FCS_T(k)
+#endif
+
 struct BwdArgsFcs {
   int N, batch, nBasis, ldbt;   // N: a multiple of L
   const double* RECS;           // scan records (ocs_scan_kernel.hpp), record of step 0
@@ -69,8 +86,10 @@ constexpr int kFcsCH = 4;   // chunks per wave (the four 16-lane rows)
 
 // W waves per workgroup of 16 trajectories, L steps per chunk: a superblock is 4 W L steps.
 // NKS: k-steps of the expansion (4 basis functions each); the gradient has NRT = ceil(NKS / 4) tiles of 16 functions.
-template <class P, int W, int L, int NKS>
-__global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
+// ABL (diagnostic builds, -DOCS_FCS_ABL): 1 no expansion products, 2 no contraction products, 3 neither, 4 no barrier,
+// 5 no phase 3, 6 no phase 1
+template <class P, int W, int L, int NKS, int ABL = 0>
+__global__ __launch_bounds__(W * 64, (NKS > 4 ? 1024 : 2048) / (W * 64)) void k_backward_fcs(const BwdArgsFcs a) {
   constexpr int NAUG = P::NAUG, CH = kFcsCH, SB = W * CH * L, NRT = (NKS + 3) / 4, NSET = (2 * L + 1 + 3) / 4;
   constexpr int NRD = (CH * L + 1 + 7) / 8;   // record DMAs per wave and superblock (8 records each)
   static_assert(P::NS == 1 && P::NC == 1 && P::NTC == 1 && P::ROW_SEPARABLE && !P::DFDU_READS_Y, "one state row per trajectory");
@@ -79,6 +98,7 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
   __shared__ __attribute__((aligned(16))) double2 sm[2][W][16];          // wave maps of a superblock
   __shared__ double csm[2][16];                                          // lam at the bottom of a superblock
   __shared__ __attribute__((aligned(16))) double rcs[2][W][NRD * 128];   // records lo_low-1 .. of a wave
+  constexpr int LDW = NKS > 4 ? 32 : 16;   // doubles per row of the basis table (= a.ldbt)
   __shared__ double red[W][NRT * 4][64];
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int lane = threadIdx.x & 63;
@@ -92,8 +112,6 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
   const double lamc = 1.0;   // lam(:, end) = e_last   RK4Integrator.m:63-69
   const size_t colB = (size_t)NAUG * B;
   const unsigned col8 = (unsigned)(colB * 8), b8 = (unsigned)((size_t)b * 8);
-  const unsigned bt8 = (unsigned)a.ldbt * 8u;
-  const Buf bbt = Buf::make(a.BT);
 
   // B operand of the expansion: k-slot g of trajectory n
   double vB[NKS];
@@ -111,18 +129,6 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
   auto wave_lo = [&](int sb) OCS_INLINE { return N - (sb * W * CH + wave * CH + CH) * L; };
   auto clamp_smp = [&](int s) OCS_INLINE { return s < 0 ? 0 : (s >= nT ? nT - 1 : s); };
 
-  double aE[NSET][NKS];   // A operands of the expansion of the NEXT superblock to process
-  auto load_aE = [&](int sb) OCS_INLINE {
-    // row i = lane & 15 = 4 m + g' is sample 4 t + m of chunk g'; this lane holds k-slot lane >> 4
-    const int gi = n & 3, mi = n >> 2;
-    const int s0 = 2 * (wave_lo(sb) + (CH - 1 - gi) * L) + mi;
-#pragma unroll
-    for (int t = 0; t < NSET; ++t) {
-      const unsigned voff = (unsigned)clamp_smp(s0 + 4 * t) * bt8 + (unsigned)g * 8u;
-#pragma unroll
-      for (int ks = 0; ks < NKS; ++ks) aE[t][ks] = bbt.ld(voff, (unsigned)(4 * ks) * 8u);
-    }
-  };
   struct Ld { double x[L]; };
   auto load_part = [&](int sb, Ld& d, int slot, int q) OCS_INLINE {
     const int lo_low = wave_lo(sb);
@@ -130,7 +136,7 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
       const int lr = lo_low - 1 >= -kScanPadFront ? lo_low - 1 : -kScanPadFront;   // (below that: zero records anyway)
 #pragma unroll
       for (int k = 0; k < NRD; ++k)
-        dma16_sc(a.RECS + (long long)lr * kScanRec + k * 128 + 2 * lane, &rcs[slot][wave][k * 128]);
+        dma16_fw(a.RECS + (long long)lr * kScanRec + k * 128 + 2 * lane, &rcs[slot][wave][k * 128]);
     }
     const int base = lo_low > 0 ? lo_low : 0;
     const int lo_g = lo_low + (CH - 1 - g) * L;
@@ -146,22 +152,47 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
   };
 
   double carry = 0.0;
+#ifdef OCS_FCS_STAMPS
+  long long seg_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, tl_ = __builtin_amdgcn_s_memtime();
+#endif
   auto process = [&](int sb, const Ld& d, int slot, Ld& dn) OCS_INLINE {
     const int lo_low = wave_lo(sb);
+    FCS_T(7);
     // everything in flight belongs to this superblock (x, expansion operands, records); the records go to LDS, which
     // the compiler's counters do not see
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // (the builtin, not inline assembly: the compiler must know that its own loads have landed too, or its counted
+    //  waits for them -- which do not count the DMAs of dma16_fw -- would wait for the DMAs issued in between)
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0)
+    asm volatile("" ::: "memory");
+    FCS_T(0);   // wait for the loads
     const double* rw = &rcs[slot][wave][0];
+    const Buf bbt = Buf::make(a.BT);
     // ---------------- the control samples of the four chunks ----------------
     double uu[2 * L + 1];
     {
+      // row i = lane & 15 = 4 m + g' is sample 4 t + m of chunk g'; this lane holds k-slot lane >> 4
+      // (read when they are needed: with four waves on a SIMD the others cover the latency, and no register waits a
+      //  superblock for its turn)
+      double aE[NSET][NKS];
+      const int s0 = 2 * (lo_low + (CH - 1 - (n & 3)) * L) + (n >> 2);
+#pragma unroll
+      for (int t = 0; t < NSET; ++t) {
+        const unsigned voff = (unsigned)clamp_smp(s0 + 4 * t) * (unsigned)(LDW * 8) + (unsigned)g * 8u;
+#pragma unroll
+        for (int ks = 0; ks < NKS; ++ks) aE[t][ks] = bbt.ld(voff, (unsigned)(4 * ks) * 8u);
+      }
       d4_fw e[NSET];
 #pragma unroll
       for (int t = 0; t < NSET; ++t) e[t] = d4_fw{0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < NKS; ++ks)
 #pragma unroll
-        for (int t = 0; t < NSET; ++t) e[t] = mma_fw(aE[t][ks], vB[ks], e[t]);
+        for (int t = 0; t < NSET; ++t) {
+          if (ABL == 1 || ABL == 3)
+            e[t] += d4_fw{aE[t][ks], vB[ks], aE[t][ks], vB[ks]};
+          else
+            e[t] = mma_fw(aE[t][ks], vB[ks], e[t]);
+        }
 #pragma unroll
       for (int t = 0; t < NSET; ++t) {
         if (4 * t + 0 <= 2 * L) uu[4 * t + 0] = e[t].x;
@@ -170,52 +201,54 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
         if (4 * t + 3 <= 2 * L) uu[4 * t + 3] = e[t].w;
       }
     }
-    load_aE(sb + 1);
-    // A operands of the contraction: k-slot lane >> 4 takes column m of chunk lane >> 4; row i = lane & 15
-    double aC[2 * L][NRT];
-    {
-      const int s0 = 2 * (lo_low + (CH - 1 - g) * L);
+    FCS_T(1);   // expansion
+    // ---------------- phase 1: stage states and the step maps ----------------
+    // lam_i = alpha_i lam_{i+1} + beta_i per step (ocs_scan_kernel.hpp); the L steps are independent of each other, the
+    // stage states and the step maps stay in registers for phase 3
 #pragma unroll
-      for (int m = 0; m < 2 * L; ++m) {
-        const unsigned voff = (unsigned)clamp_smp(s0 + m) * bt8 + (unsigned)n * 8u;
+    for (int q = 0; q < L; ++q) load_part(sb + 1, dn, slot ^ 1, q);
+    // (the stage states are formed again in phase 3: nine operations per step against six registers per step, which
+    //  decide between three and four waves per SIMD)
+    double al[L], be[L];
 #pragma unroll
-        for (int rt = 0; rt < NRT; ++rt) aC[m][rt] = bbt.ld(voff, (unsigned)(16 * rt) * 8u);
+    for (int q = 0; q < L; ++q) {
+      if (ABL == 6) {
+        al[q] = uu[2 * q + 2] + d.x[q]; be[q] = 1.0;
+        continue;
       }
-    }
-    // ---------------- phase 1: stage states and the chunk map ----------------
-    double A = 1.0, Bq = 0.0;
-#pragma unroll
-    for (int q = L - 1; q >= 0; --q) {
       const Rc c = rec_of(rw, q);
       const double xi = d.x[q], uA = uu[2 * q], uM = uu[2 * q + 1], uB = uu[2 * q + 2];
       double f = P::g_row_f(xi, uA, c.tA, rp);                 // compute_states :39-46
-      const double Y2 = __builtin_fma(c.hh, f, xi);
-      f = P::g_row_f(Y2, uM, c.tM, rp);
-      const double Y3 = __builtin_fma(c.hh, f, xi);
-      f = P::g_row_f(Y3, uM, c.tM, rp);
-      const double Y4 = __builtin_fma(c.h, f, xi);
+      const double Y2q = __builtin_fma(c.hh, f, xi);
+      f = P::g_row_f(Y2q, uM, c.tM, rp);
+      const double Y3q = __builtin_fma(c.hh, f, xi);
+      f = P::g_row_f(Y3q, uM, c.tM, rp);
+      const double Y4q = __builtin_fma(c.h, f, xi);
       const Stage s4 = P::template stage<false>(c.s4, c.h6, c.tB, lamc), s3 = P::template stage<false>(c.s3, c.h3, c.tM, lamc),
                   s1 = P::template stage<false>(c.s1, c.h6, c.tA, lamc);
       double a4, b4, a3, b3, a2, b2, a1, b1;                    // (p, q): the quantity is p lam_{i+1} + q   :73-88
-      P::g_row_dfdx_pre(Y4, uB, s4, rp, a4, b4);
+      P::g_row_dfdx_pre(Y4q, uB, s4, rp, a4, b4);
       const double g3p = a4 * c.h6, g3q = b4;
       const double k3p = __builtin_fma(c.h, g3p, c.h3), k3q = c.h * g3q;
-      P::g_row_dfdx_pre(Y3, uM, s3, rp, a3, b3);
+      P::g_row_dfdx_pre(Y3q, uM, s3, rp, a3, b3);
       const double g2p = a3 * k3p, g2q = __builtin_fma(a3, k3q, b3);
       const double k2p = __builtin_fma(c.hh, g2p, c.h3), k2q = c.hh * g2q;
-      P::g_row_dfdx_pre(Y2, uM, s3, rp, a2, b2);
+      P::g_row_dfdx_pre(Y2q, uM, s3, rp, a2, b2);
       const double g1p = a2 * k2p, g1q = __builtin_fma(a2, k2q, b2);
       const double k1p = __builtin_fma(c.hh, g1p, c.h6), k1q = c.hh * g1q;
       P::g_row_dfdx_pre(xi, uA, s1, rp, a1, b1);
       const double g0p = a1 * k1p, g0q = __builtin_fma(a1, k1q, b1);
-      const double alpha = (((1.0 + g1p) + g2p) + g3p) + g0p;
-      const double beta = ((g1q + g2q) + g3q) + g0q;
-      Bq = __builtin_fma(alpha, Bq, beta);
-      A = alpha * A;
-      __builtin_amdgcn_sched_barrier(0);
-      load_part(sb + 1, dn, slot ^ 1, L - 1 - q);
-      __builtin_amdgcn_sched_barrier(0);
+      al[q] = (((1.0 + g1p) + g2p) + g3p) + g0p;
+      be[q] = ((g1q + g2q) + g3q) + g0q;
     }
+    double A = al[L - 1], Bq = be[L - 1];   // the chunk: lam at its bottom = A lam at its top + Bq
+#pragma unroll
+    for (int q = L - 2; q >= 0; --q) {
+      Bq = __builtin_fma(al[q], Bq, be[q]);
+      A = al[q] * A;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    FCS_T(2);   // phase 1
     // ---------------- the maps of the chunks above, inside the wave ----------------
     // chunk g maps lam at its top to lam at its bottom: (A, Bq).  With e / o the maps of the even / odd chunk of the own
     // pair and P01 = chunk 1 after chunk 0, P23 = chunk 3 after chunk 2:
@@ -232,7 +265,9 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
     const double EA = g == 0 ? 1.0 : g == 1 ? eA : g == 2 ? p01A : e3A;
     const double EB = g == 0 ? 0.0 : g == 1 ? eB : g == 2 ? p01B : e3B;
     if (g == 0) sm[sb & 1][wave][n] = double2{TA, TB};
-    lds_barrier_sc();
+    FCS_T(3);   // maps inside the wave
+    if (ABL != 4) lds_barrier_sc();
+    FCS_T(4);   // barrier
     // ---------------- phase 2: lam at the top of this chunk ----------------
     double lam = (sb == 0) ? 0.0 : csm[(sb & 1) ^ 1][n];
 #pragma unroll
@@ -244,65 +279,84 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
       }
     }
     lam = __builtin_fma(EA, lam, EB);
-    // ---------------- phase 3: the recursion inside the chunk, the columns of dJdu ----------------
-    double col[2 * L], ctop = 0.0, pend = 0.0;
+    // ---------------- phase 3: lam above every step, then the columns of dJdu (the steps independent again) -------------
+    double lt[L];   // lam(i+1) for step i = lo + q
+    lt[L - 1] = lam;
 #pragma unroll
-    for (int q = L - 1; q >= 0; --q) {
+    for (int q = L - 1; q >= 1; --q) lt[q - 1] = __builtin_fma(al[q], lt[q], be[q]);
+    lam = __builtin_fma(al[0], lt[0], be[0]);   // lam at the bottom of the chunk
+    double col[2 * L], ctop = 0.0, pk1[L], p4s[L];
+#pragma unroll
+    for (int q = 0; q < L; ++q) {
+      if (ABL == 5) {
+        p4s[q] = lt[q]; col[2 * q + 1] = al[q]; pk1[q] = be[q];
+        continue;
+      }
       const Rc c = rec_of(rw, q);
       const double xi = d.x[q], uA = uu[2 * q], uM = uu[2 * q + 1], uB = uu[2 * q + 2];
       double f = P::g_row_f(xi, uA, c.tA, rp);
-      const double Y2 = __builtin_fma(c.hh, f, xi);
-      f = P::g_row_f(Y2, uM, c.tM, rp);
-      const double Y3 = __builtin_fma(c.hh, f, xi);
-      f = P::g_row_f(Y3, uM, c.tM, rp);
-      const double Y4 = __builtin_fma(c.h, f, xi);
+      const double Y2q = __builtin_fma(c.hh, f, xi);
+      f = P::g_row_f(Y2q, uM, c.tM, rp);
+      const double Y3q = __builtin_fma(c.hh, f, xi);
+      f = P::g_row_f(Y3q, uM, c.tM, rp);
+      const double Y4q = __builtin_fma(c.h, f, xi);
       const Stage s4 = P::template stage<false>(c.s4, c.h6, c.tB, lamc), s3 = P::template stage<false>(c.s3, c.h3, c.tM, lamc),
                   s1 = P::template stage<false>(c.s1, c.h6, c.tA, lamc);
-      const double h6l = c.h6 * lam, h3l = c.h3 * lam;
-      const double k4 = h6l;                                     // :73
-      const double g3 = P::g_row_dfdx(Y4, uB, k4, s4, rp);       // :74-75
-      const double k3 = __builtin_fma(c.h, g3, h3l);             // :77
-      const double g2 = P::g_row_dfdx(Y3, uM, k3, s3, rp);       // :78-79
-      const double k2 = __builtin_fma(c.hh, g2, h3l);            // :81
-      const double g1 = P::g_row_dfdx(Y2, uM, k2, s3, rp);       // :82-83
-      const double k1 = __builtin_fma(c.hh, g1, h6l);            // :85
-      const double g0 = P::g_row_dfdx(xi, uA, k1, s1, rp);       // :87-88
-      lam = (((lam + g1) + g2) + g3) + g0;                       // :86-88
+      const double h6l = c.h6 * lt[q], h3l = c.h3 * lt[q];
+      const double k4 = h6l;                                        // :73
+      const double g3 = P::g_row_dfdx(Y4q, uB, k4, s4, rp);       // :74-75
+      const double k3 = __builtin_fma(c.h, g3, h3l);                // :77
+      const double g2 = P::g_row_dfdx(Y3q, uM, k3, s3, rp);       // :78-79
+      const double k2 = __builtin_fma(c.hh, g2, h3l);               // :81
+      const double g1 = P::g_row_dfdx(Y2q, uM, k2, s3, rp);       // :82-83
+      const double k1 = __builtin_fma(c.hh, g1, h6l);               // :85
       // compute_dJdu :97-121: column 2i+1 = B'k2 + B'k3; column 2i+2 = B'k4 of step i + B'k1 of step i+1 -- the latter
       // belongs to the chunk of step i+1 (its lowest column) except column 2N
-      const double p4 = P::g_row_dfdu(Y4, uB, k4, s4, rp);
-      const double p23 = P::g_row_dfdu(Y3, uM, k3, s3, rp) + P::g_row_dfdu(Y2, uM, k2, s3, rp);
-      col[2 * q + 1] = p23;
-      if (q == L - 1)
-        ctop = pend + p4;       // (pend = 0: RK4Integrator.m:119-120)
-      else
-        col[2 * q + 2] = pend + p4;
-      pend = P::g_row_dfdu(xi, uA, k1, s1, rp);
-      if (q == 0) {
-        // column 2 lo = B'k1 of step lo + B'k4 of step lo-1 (k4 = h/6 lam_lo); column 0 has the k1 half only :101-102
-        const Rc cb = rec_of(rw, -1);
-        const Stage sb4 = P::template stage<false>(cb.s4, cb.h6, cb.tB, lamc);
-        col[0] = pend + P::g_row_dfdu(0.0, uA, cb.h6 * lam, sb4, rp);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+      p4s[q] = P::g_row_dfdu(Y4q, uB, k4, s4, rp);
+      col[2 * q + 1] = P::g_row_dfdu(Y3q, uM, k3, s3, rp) + P::g_row_dfdu(Y2q, uM, k2, s3, rp);
+      pk1[q] = P::g_row_dfdu(xi, uA, k1, s1, rp);
     }
+#pragma unroll
+    for (int q = 0; q + 1 < L; ++q) col[2 * q + 2] = pk1[q + 1] + p4s[q];
+    ctop = p4s[L - 1];          // (the k1 half of column 2N is zero: RK4Integrator.m:119-120)
+    {
+      // column 2 lo = B'k1 of step lo + B'k4 of step lo-1 (k4 = h/6 lam_lo); column 0 has the k1 half only :101-102
+      const Rc cb = rec_of(rw, -1);
+      const Stage sb4 = P::template stage<false>(cb.s4, cb.h6, cb.tB, lamc);
+      col[0] = pk1[0] + P::g_row_dfdu(0.0, uu[0], cb.h6 * lam, sb4, rp);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    FCS_T(5);   // phases 2 and 3
     // ---------------- dJdv += dJdu(:, j) B(:, j)' ----------------
+    // A operands: k-slot lane >> 4 takes column m of chunk lane >> 4; row i = lane & 15
+    double aC[2 * L][NRT];
+#pragma unroll
+    for (int m = 0; m < 2 * L; ++m) {
+      const unsigned voff = (unsigned)clamp_smp(2 * (lo_low + (CH - 1 - g) * L) + m) * (unsigned)(LDW * 8) + (unsigned)n * 8u;
+#pragma unroll
+      for (int rt = 0; rt < NRT; ++rt) aC[m][rt] = bbt.ld(voff, (unsigned)(16 * rt) * 8u);
+    }
 #pragma unroll
     for (int m = 0; m < 2 * L; ++m)
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) acc[rt] = mma_fw(aC[m][rt], col[m], acc[rt]);
+      for (int rt = 0; rt < NRT; ++rt) {
+        if (ABL == 2 || ABL == 3)
+          acc[rt] += d4_fw{aC[m][rt], col[m], aC[m][rt], col[m]};
+        else
+          acc[rt] = mma_fw(aC[m][rt], col[m], acc[rt]);
+      }
     if (sb == 0 && wave == 0) {   // column 2N, from the topmost chunk
-      const unsigned voff = (unsigned)(nT - 1) * bt8 + (unsigned)n * 8u;
 #pragma unroll
-      for (int rt = 0; rt < NRT; ++rt) acc[rt] = mma_fw(bbt.ld(voff, (unsigned)(16 * rt) * 8u), g == 0 ? ctop : 0.0, acc[rt]);
+      for (int rt = 0; rt < NRT; ++rt)
+        acc[rt] = mma_fw(a.BT[(size_t)(nT - 1) * LDW + 16 * rt + n], g == 0 ? ctop : 0.0, acc[rt]);
     }
     if (wave == W - 1 && g == CH - 1) csm[sb & 1][n] = lam;   // lam at the bottom of the superblock
     carry = lam;
+    FCS_T(6);   // contraction
   };
 
   const int nsb = (N + SB - 1) / SB;
   Ld d0, d1;
-  load_aE(0);
 #pragma unroll
   for (int q = 0; q < L; ++q) load_part(0, d0, 0, q);
   for (int sb = 0; sb < nsb; sb += 2) {
@@ -313,6 +367,10 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
     a.lam0[b] = carry;
     a.lam0[B + b] = lamc;
   }
+#ifdef OCS_FCS_STAMPS
+  if (blockIdx.x == 0 && lane == 0)
+    for (int k = 0; k < 8; ++k) g_fcs_stamp[wave * 8 + k] = seg_[k];
+#endif
   // the W partial gradients of the workgroup's 16 trajectories
 #pragma unroll
   for (int rt = 0; rt < NRT; ++rt) {
@@ -339,7 +397,7 @@ __global__ __launch_bounds__(W * 64) void k_backward_fcs(const BwdArgsFcs a) {
 // ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
-constexpr int kFcsW = 4, kFcsL = 4;
+constexpr int kFcsW = 8, kFcsL = 4;
 
 bool fused_wave_supported(Functor f, int nS, int nC, int nBasis, int N, int batch) {
   // state pass: whole blocks of 8 steps, whole tiles of 64 / nS trajectories; adjoint pass: one state row
@@ -347,18 +405,37 @@ bool fused_wave_supported(Functor f, int nS, int nC, int nBasis, int N, int batc
          batch % 64 == 0 && (size_t)batch * 16u * 16u < 0x7FFFFFF0u;
 }
 
-template <class P, int NKS>
-static void run_forward_fcw(const FwdArgsP2& a, bool uniform, hipStream_t s) {
-  using C_ = P2Cfg<P::NS, NKS>;
+template <class P, int NKS, int TPW>
+static void run_forward_fcw_t(const FwdArgsP2& a, bool uniform, hipStream_t s) {
+  using C_ = P2Cfg<P::NS, NKS, TPW>;
   const dim3 grid(a.batch / C_::TPW), block(C_::NWAVE * 64);
   if (uniform)
-    k_forward_p2<P, true, false, true, NKS><<<grid, block, 0, s>>>(a);
+    k_forward_p2<P, true, false, true, NKS, TPW><<<grid, block, 0, s>>>(a);
   else
-    k_forward_p2<P, true, false, false, NKS><<<grid, block, 0, s>>>(a);
+    k_forward_p2<P, true, false, false, NKS, TPW><<<grid, block, 0, s>>>(a);
+}
+// Half tiles (32 trajectories per workgroup) while that fills the chip at most twice: the waves beside the recursion wave
+// (objective, expansion: three quarters of the fp64 work of a block) then have half the work per CU, and the pass runs
+// at the pace of the recursion (measured at batch 8192, N = 1000: 97 us with 64-trajectory tiles).
+template <class P, int NKS>
+static void run_forward_fcw(const FwdArgsP2& a, bool uniform, hipStream_t s) {
+  if (a.batch / 32 <= 512)
+    run_forward_fcw_t<P, NKS, 32>(a, uniform, s);
+  else
+    run_forward_fcw_t<P, NKS, 64>(a, uniform, s);
 }
 template <class P, int NKS>
 static void run_backward_fcs(const BwdArgsFcs& a, hipStream_t s) {
-  k_backward_fcs<P, kFcsW, kFcsL, NKS><<<dim3((a.batch + 15) / 16), dim3(kFcsW * 64), 0, s>>>(a);
+  const dim3 grid((a.batch + 15) / 16), block(kFcsW * 64);
+#ifdef OCS_FCS_ABL
+  static const int abl = getenv("OCS_FCS_ABL") ? atoi(getenv("OCS_FCS_ABL")) : 0;
+  if (NKS == 4) {
+#define OCS_ABL_CASE(K) if (abl == K) return (void)(k_backward_fcs<P, kFcsW, kFcsL, 4, K><<<grid, block, 0, s>>>(a));
+    OCS_ABL_CASE(1) OCS_ABL_CASE(2) OCS_ABL_CASE(3) OCS_ABL_CASE(4) OCS_ABL_CASE(5) OCS_ABL_CASE(6)
+#undef OCS_ABL_CASE
+  }
+#endif
+  k_backward_fcs<P, kFcsW, kFcsL, NKS><<<grid, block, 0, s>>>(a);
 }
 
 // BT: [2N+1][ldbt] (ldbt = 16 or 32: the fused-control layout of ocs_control.cpp)
@@ -374,6 +451,20 @@ int launch_forward_fcw(const ProblemDesc& p, const GridDesc& g, int batch, int n
     case 4: run_forward_fcw<LogisticK<1>, 4>(a, g.uniform, s); break;
     default: run_forward_fcw<LogisticK<1>, 8>(a, g.uniform, s); break;
   }
+#ifdef OCS_P2_STAMPS
+  {   // diagnostic build: cycles of every role of workgroup 0 (barrier wait / total), roles as in P2Cfg::role
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      (void)hipStreamSynchronize(s);
+      long long h[64];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_p2_stamp), sizeof(h));
+      fprintf(stderr, "[p2 fcw batch %d] role: barrier wait / total cycles:", batch);
+      const char* names[10] = {"M", "S", "C0", "C1", "C2", "C3", "J", "P", "U0", "U1"};
+      for (int w = 0; w < 10; ++w) fprintf(stderr, " %s %lld/%lld", names[w], h[4 * w], h[4 * w + 1]);
+      fprintf(stderr, "\n");
+    }
+  }
+#endif
   return hip_rc_fw(hipGetLastError());
 }
 int launch_backward_fcs(const ProblemDesc& p, const GridDesc& g, int batch, int nBasis, int ldbt, const double* BT,
@@ -389,6 +480,19 @@ int launch_backward_fcs(const ProblemDesc& p, const GridDesc& g, int batch, int 
     case 4: run_backward_fcs<LogisticK<1>, 4>(a, s); break;
     default: run_backward_fcs<LogisticK<1>, 8>(a, s); break;
   }
+#ifdef OCS_FCS_STAMPS
+  {
+    static int calls = 0;
+    if (++calls % 8 == 0) {
+      (void)hipStreamSynchronize(s);
+      long long h[64];
+      (void)hipMemcpyFromSymbol(h, HIP_SYMBOL(g_fcs_stamp), sizeof(h));
+      for (int w = 0; w < kFcsW; ++w)
+        fprintf(stderr, "[fcs batch %d wave %d] wait %lld expansion %lld phase1 %lld maps %lld barrier %lld phase2+3 %lld contraction %lld other %lld\n",
+                batch, w, h[8 * w], h[8 * w + 1], h[8 * w + 2], h[8 * w + 3], h[8 * w + 4], h[8 * w + 5], h[8 * w + 6], h[8 * w + 7]);
+    }
+  }
+#endif
   return hip_rc_fw(hipGetLastError());
 }
 

@@ -79,10 +79,15 @@ struct BufP2 {
 // NKS > 0: the control samples are not read from memory but expanded in the kernel from the coefficients of a dense
 // basis, u(:, j) = sum_k v_k B(k, j) (Control/ChebyshevControl.m:35-38), by NUW waves on the matrix cores: NKS k-steps of
 // v_mfma_f64_16x16x4_f64 per tile of 16 samples x 16 trajectories (role U below).  Only the step records are streamed then.
-template <int G, int NKS = 0>
+// TPW_: trajectories per workgroup, 64 / G by default (every lane of the recursion wave owns one state row).  Half of
+// that (G = 1, TPW_ = 32: the upper half of the recursion wave repeats the lower) halves everything a workgroup does
+// besides the recursion -- for batches that leave CUs idle, where the other waves of the CU set the pace.
+template <int G, int NKS = 0, int TPW_ = 64 / G>
 struct P2Cfg {
   static constexpr int D = 8;                        // steps per block
-  static constexpr int TPW = 64 / G;                 // trajectories per workgroup
+  static constexpr int TPW = TPW_;                   // trajectories per workgroup
+  static constexpr int GS = 64 / TPW;                // lane groups of a wave (objective waves: steps per pass)
+  static_assert(GS * TPW == 64 && GS % G == 0 && GS <= 4, "lane groups");
   static constexpr int Q = NKS > 0 ? 2 : (G == 1) ? 6 : 8;   // blocks the DMA runs ahead of the preparation (an interval is
                                                      // ~0.3 us: HBM latency needs several; vmcnt counts to 63; the record
                                                      // table alone is shared by all workgroups and sits in L2)
@@ -92,14 +97,14 @@ struct P2Cfg {
   static constexpr int U_DBL = 2 * D * TPW, NU = U_DBL / 128;
   static constexpr int SLOT = REC_DBL + U_DBL;
   static constexpr int LPB = NREC + (NKS > 0 ? 0 : NU);
-  static constexpr int NCW = (G == 4) ? 2 : 4;       // objective/store waves
+  static constexpr int NCW = (GS == 4) ? 2 : 4;      // objective/store waves
   static constexpr int SPW = D / NCW;                // steps per such wave and block
-  static constexpr int NPASS = SPW / G > 0 ? SPW / G : 1;
+  static constexpr int NPASS = SPW / GS > 0 ? SPW / GS : 1;
   static constexpr int NT = TPW / 16;                // tiles of 16 trajectories (NKS > 0)
-  static constexpr int NUW = NKS > 0 ? (G == 1 ? 2 : 1) : 0;   // expansion waves
+  static constexpr int NUW = NKS > 0 ? (NT >= 2 ? 2 : 1) : 0;   // expansion waves
   static constexpr int TW = NKS > 0 ? NT / NUW : 0;  // tiles per expansion wave
   static constexpr int NWAVE = 4 + NCW + NUW;        // M, S, C.., J, P (, U..)
-  static_assert(REC_DBL % 128 == 0 && U_DBL % 128 == 0 && (SPW % G == 0 || G > SPW), "block shapes");
+  static_assert(REC_DBL % 128 == 0 && U_DBL % 128 == 0 && (SPW % GS == 0 || GS > SPW), "block shapes");
   static_assert(NKS == 0 || (2 * D == 16 && NT >= 1 && NKS <= 8), "a block of samples is one 16-row tile");
   // role of a wave (0 M, 1 S, 2.. C, 2 + NCW J, 3 + NCW P, 4 + NCW.. U).  A workgroup's waves are dealt to the four
   // SIMDs in turn (wave w and w + 4 share one): with the expansion waves present the recursion wave gets the SIMD of
@@ -107,8 +112,9 @@ struct P2Cfg {
   __device__ static constexpr int role(int w) {
     if (NKS == 0) return w;
     constexpr int M_ = 0, S_ = 1, C_ = 2, J_ = 2 + NCW, P_ = 3 + NCW, U_ = 4 + NCW;
-    if (G == 1) { constexpr int r[10] = {U_, U_ + 1, S_, J_, C_, C_ + 1, M_, P_, C_ + 2, C_ + 3}; return r[w]; }
-    if (G == 2) { constexpr int r[9] = {U_, C_, S_, C_ + 2, J_, C_ + 1, M_, C_ + 3, P_}; return r[w]; }
+    // (a matrix instruction occupies the SIMD's fp64 datapath for its 64 cycles: an expansion wave gets ONE objective
+    //  wave beside it, the two remaining objective waves share the fourth SIMD)
+    if (NWAVE == 10) { constexpr int r[10] = {U_, U_ + 1, S_, C_ + 2, C_, C_ + 1, M_, C_ + 3, J_, P_}; return r[w]; }
     constexpr int r[7] = {U_, C_, S_, C_ + 1, J_, P_, M_};
     return r[w];
   }
@@ -136,11 +142,12 @@ struct FwdArgsP2 {
 };
 
 // UNI: uniform grid -- the step sizes are the same for every step and stay in registers
-template <class P, bool OUT_X, bool FRZ, bool UNI, int NKS = 0>
-__global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(const FwdArgsP2 a) {
-  constexpr int G = P::NS, NAUG = P::NAUG;
+template <class P, bool OUT_X, bool FRZ, bool UNI, int NKS = 0, int TPW_ = 64 / P::NS>
+__global__ __launch_bounds__((P2Cfg<P::NS, NKS, TPW_>::NWAVE * 64)) void k_forward_p2(const FwdArgsP2 a) {
+  constexpr int G = P::NS, NAUG = P::NAUG;   // G: state rows
   static_assert(P::NC == 1 && P::NTC == 1, "pipeline kernels: one control, one time coefficient");
-  using C_ = P2Cfg<G, NKS>;
+  using C_ = P2Cfg<G, NKS, TPW_>;
+  constexpr int GS = C_::GS;                 // lane groups of a wave: G rows of TPW trajectories, repeated GS / G times
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
   constexpr int NCW = C_::NCW, SPW = C_::SPW;
   __shared__ __attribute__((aligned(16))) double inp[NSLOT][C_::SLOT];   // {records | u}
@@ -159,8 +166,7 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(
 
   if (wave == 0) {
     // ---------------- M/P: HBM -> LDS, and the control terms of the next block for S ----------------
-    const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
-    (void)r; (void)b;
+
     // (ring positions are carried along instead of taken as remainders: a wave's time is its instruction count)
     int cI = 0;   // ring position of the next block to issue (blocks are issued in order)
     auto issue = [&](int j) OCS_INLINE {
@@ -205,7 +211,7 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(
     P2_END(0);
   } else if (wave == 1) {
     // ---------------- S: the recursion ----------------
-    const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
+    const int r = (lane / TPW) % G, tl = lane % TPW, b = bw + tl;   // (GS > G: the upper lane groups repeat the lower)
     const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
     const bool fz = FRZ && a.frozen != nullptr && a.frozen[b] != 0;
     const double mh = P::HAS_SHIFT ? P::row_shift(rp) : 0.0;
@@ -329,8 +335,8 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(
         const BufP2 bx = BufP2::make(a.x + (size_t)(j * D) * colB);
 #pragma unroll
         for (int p = 0; p < C_::NPASS; ++p) {
-          const int s0 = cw * SPW + p * G;     // wave-uniform first step of the pass
-          const int s = s0 + csub;             // this lane's step (csub < G)
+          const int s0 = cw * SPW + p * GS;    // wave-uniform first step of the pass
+          const int s = s0 + csub;             // this lane's step (csub < GS)
           const double wA = rec[RS * s + SCO + 3], wM = rec[RS * s + SCO + 4], wB = rec[RS * s + SCO + 5];
           const double h = UNI ? hU : rec[RS * s], hh = UNI ? hhU : rec[RS * s + 1];
           const double uM = us[(2 * s) * TPW], uB = us[(2 * s + 1) * TPW];
@@ -383,16 +389,16 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(
             }
             d = h6 * (__builtin_fma(2.0, q3, __builtin_fma(2.0, q2, q1)) + q4);
           }
-          if (csub < G) dd[j & 1][s][ctl] = d;
+          if (csub < GS) dd[j & 1][s][ctl] = d;
         }
       }
     }
     P2_END(wave);
   } else if (wave == 2 + NCW) {
     // ---------------- J: running objective ----------------
-    // lane (sg, tl): SPJ = D / G consecutive steps of trajectory tl, starting at step sg SPJ; the sum over the lanes
+    // lane (sg, tl): SPJ = D / GS consecutive steps of trajectory tl, starting at step sg SPJ; the sum over the lanes
     // of a trajectory through the LDS crossbar
-    constexpr int SPJ = D / G;
+    constexpr int SPJ = D / GS;
     const int sg = lane / TPW, tl = lane % TPW, b = bw + tl;
     const bool fz = FRZ && a.frozen != nullptr && a.frozen[b] != 0;
     const bool wc = OUT_X && !a.nocost;
@@ -413,11 +419,11 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(
         // exclusive prefix of the group totals over sg, and the block total
         const double tot = pre[SPJ - 1];
         double excl = 0.0;
-        if (G >= 2) {
+        if (GS >= 2) {
           const int below = (lane + 64 - TPW) & 63;                      // the lane of group sg-1
           const double t1 = __shfl(tot, below);
           double inc = tot + (sg >= 1 ? t1 : 0.0);                       // inclusive over two groups
-          if (G == 4) {
+          if (GS == 4) {
             const double t2 = __shfl(inc, (lane + 64 - 2 * TPW) & 63);   // from group sg-2
             inc += (sg >= 2 ? t2 : 0.0);
           }
@@ -430,7 +436,7 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(
         for (int q = 0; q < SPJ; ++q) bx.st_nt(base + pre[q], vj, (unsigned)q * col8);   // objective at node i+1
         // the next block starts from the value stored for this block's last node (so that J == x(end, end) bit for bit)
         const double lastv = base + pre[SPJ - 1];
-        carry = (G == 1) ? lastv : __shfl(lastv, (G - 1) * TPW + tl);
+        carry = (GS == 1) ? lastv : __shfl(lastv, (GS - 1) * TPW + tl);
       }
     }
     P2_END(wave);
@@ -439,7 +445,7 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS>::NWAVE * 64)) void k_forward_p2(
     // ---------------- P: the control terms of the next block for S ----------------
     // P::row_vertex(m_r/2, u) = m_r^2/4 - u for the two new samples of every step, per S lane: two instructions less
     // on the recursion wave, which is bound by its instruction count
-    const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
+    const int r = (lane / TPW) % G, tl = lane % TPW, b = bw + tl;
     const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
     const double mh = P::HAS_SHIFT ? P::row_shift(rp) : 0.0;
     int cQ = 0;   // ring position of block j of the next call of prepare

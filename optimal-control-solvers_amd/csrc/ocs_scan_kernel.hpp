@@ -128,7 +128,8 @@ __device__ static inline void dma16_sc(const double* src, double* lds_base) {
 }
 
 constexpr int kScanRec = 16;       // doubles per record: {h, h/2, h/6, h/3 | s4, s3, s1, 0 | tcA, tcM, tcB, 0 | pad}
-constexpr int kScanPadFront = 80;  // zero records before step 0 (>= W L + 1)
+constexpr int kScanPadFront = 136; // zero records before step 0 (>= the steps of a superblock + 1: 16 x 4 in
+                                   // k_backward_scan, 8 x 4 x 4 in k_backward_fcs)
 constexpr int kScanPadBack = 8;    // and after step N-1 (a wave copies 8 records per chunk)
 
 // W waves per workgroup (chunks per superblock), L steps per chunk

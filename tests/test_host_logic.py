@@ -99,7 +99,7 @@ def test_registry_and_option_validation_without_gpu(ocs):
     import oracle.oracle as orc0
     t = _grid(orc0, 40, 4.0)
     c = ocs.ChebyshevControl(t, 6, 1)
-    for mode in ("auto", "off", "on"):
+    for mode in ("auto", "off", "on", "lane"):
         assert c.set_fusion(mode) is c
     assert _lib.lib.ocs_control_set_fusion(c._h, 7) == -1      # OCS_ERR_INVALID
     # MATLAB linspace: end points pinned, (k*(b-a))/(n-1) rounding (differs from numpy's start + k*step)
