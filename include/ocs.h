@@ -107,8 +107,11 @@ int ocs_problem_dFdu_times_vec(ocs_problem p, int k, const double *t, const doub
  * Steady state of the optimality system, one instance per trajectory of the batch (per-trajectory parameters of `p`
  * apply): y = [x; lam; u] with n = 2 nS + nC entries.  Device arrays, batch-minor: yGuess, y, residual [n][batch];
  * lb, ub [n] (shared, as in the reference's call); resnorm [batch] (squared 2-norm of the residual, lsqnonlin's
- * resnorm); exitflag [batch] (1 converged, 0 iteration limit).  residual may be NULL.  The host variant takes
- * MATLAB-shaped arrays (n x batch, column-major) and batch = 1 reproduces the reference call.
+ * resnorm); exitflag [batch] (1 converged, 0 iteration limit, -1 the residual is not finite at the clamped guess or
+ * became so: lsqnonlin raises an error there, nothing is reported as a solution).  residual may be NULL.  The host
+ * variant takes MATLAB-shaped arrays (n x batch, column-major), batch = 1 reproduces the reference call, and it
+ * returns OCS_NUM_NONFINITE when some instance has exitflag -1 (the device variant leaves that to the caller: it does
+ * not synchronise).  A variable with lb == ub stays fixed.
  * lsqnonlin is a MATLAB toolbox: the iteration here is a projected Levenberg-Marquardt with the reference's residual
  * (:13-21); the root found from the same guess is the same.  Registry problems with nS <= 4 and user problems. */
 int ocs_compute_equilibrium_dev(ocs_problem p, int batch, double r, const double *yGuess, const double *lb,

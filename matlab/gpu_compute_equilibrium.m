@@ -10,6 +10,6 @@ function [xStar, lamStar, uStar, resnorm, residual, exitflag] = ...
    resnorm = zeros(batch, 1);  exitflag = zeros(batch, 1, 'int32');
    [rc, ~, ~, ~, ~, y, resnorm, residual, exitflag] = calllib('libocs', 'ocs_compute_equilibrium', ...
          prob.h.Value, batch, r, yG, lb, ub, y, resnorm, residual, exitflag);
-   ocs_check(rc);
+   ocs_check(rc);     % rc > 0 (OCS_NUM_NONFINITE): some instance has exitflag -1 (undefined values; lsqnonlin errors there)
    xStar = y(1:nS, :);  lamStar = y(nS+1:2*nS, :);  uStar = y(2*nS+1:end, :);   % :29-31
 end

@@ -237,6 +237,8 @@ int ocs_compute_equilibrium(ocs_problem p, int batch, double r, const double* yG
     }
     HIP_TRY(hipMemcpy(resnorm, dr.p, sizeof(double) * batch, hipMemcpyDeviceToHost));
     HIP_TRY(hipMemcpy(exitflag, df.p, sizeof(int) * batch, hipMemcpyDeviceToHost));
+    for (int b = 0; b < batch; ++b)
+      if (exitflag[b] < 0) return OCS_NUM_NONFINITE;   // (a numerical condition: the outputs of the other instances stand)
     return OCS_OK;
   };
   const int rc = body();

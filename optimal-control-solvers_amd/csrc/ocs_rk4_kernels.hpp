@@ -529,7 +529,9 @@ struct EqArgs {
   double* y;             // [n][B]
   double* resnorm;       // [B] squared 2-norm of the residual
   double* residual;      // [n][B] or nullptr
-  int* exitflag;         // [B]: 1 converged (residual at round-off or no further decrease possible), 0 iteration limit
+  int* exitflag;         // [B]: 1 converged (residual at round-off or no further decrease possible), 0 iteration limit,
+                         //      -1 the residual is not finite at the (clamped) guess or became so (lsqnonlin raises an
+                         //      error on undefined values, compute_equilibrium.m:27: never reported as a solution)
   int max_iter;
   double tol;            // stop when the max-norm of the residual is below tol (relative to max(1, |terms|))
 };
@@ -568,14 +570,20 @@ __global__ __launch_bounds__(64) void k_equilibrium(const EqArgs a) {
   for (int k = 0; k < NV; ++k) {
     lo[k] = a.lb[k];
     hi[k] = a.ub[k];
-    y[k] = fmin(hi[k], fmax(lo[k], a.y0[(size_t)k * B + b]));
+    const double g0 = a.y0[(size_t)k * B + b];
+    y[k] = g0 != g0 ? g0 : fmin(hi[k], fmax(lo[k], g0));   // (fmin / fmax would replace a NaN guess by a bound)
   }
   residual(y, R);
   double cost = 0.0;
   for (int k = 0; k < NV; ++k) cost += R[k] * R[k];
+  for (int k = 0; k < NV; ++k) cost += (y[k] != y[k]) ? y[k] : 0.0;   // a NaN guess: not a point to start from
   double mu = 1e-3;
   int flag = 0;
   for (int it = 0; it < a.max_iter; ++it) {
+    if (!isfinite(cost)) {   // (fmax below would drop a NaN and report convergence)
+      flag = -1;
+      break;
+    }
     double rmax = 0.0;
     for (int k = 0; k < NV; ++k) rmax = fmax(rmax, fabs(R[k]));
     if (rmax <= a.tol) {
@@ -590,6 +598,10 @@ __global__ __launch_bounds__(64) void k_equilibrium(const EqArgs a) {
       for (int k = 0; k < NV; ++k) yp[k] = ym[k] = y[k];
       yp[j] = fmin(hi[j], y[j] + hstep);
       ym[j] = fmax(lo[j], y[j] - hstep);
+      if (!(yp[j] > ym[j])) {   // a variable fixed by lb == ub: no column (it is frozen below)
+        for (int k = 0; k < NV; ++k) Jm[k][j] = 0.0;
+        continue;
+      }
       residual(yp, Rp);
       residual(ym, Rm);
       const double inv = 1.0 / (yp[j] - ym[j]);
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(64) void k_equilibrium(const EqArgs a) {
     for (int tries = 0; tries < 12 && !improved; ++tries) {
       double M[NV][NV + 1];
       for (int i = 0; i < NV; ++i) {
-        const bool frozen = (y[i] <= lo[i] && gv[i] > 0.0) || (y[i] >= hi[i] && gv[i] < 0.0);
+        const bool frozen = (y[i] <= lo[i] && gv[i] > 0.0) || (y[i] >= hi[i] && gv[i] < 0.0) || !(hi[i] > lo[i]);
         for (int j = 0; j < NV; ++j) M[i][j] = frozen ? (i == j ? 1.0 : 0.0) : Am[i][j];
         if (!frozen) M[i][i] += mu * fmax(Am[i][i], 1e-300);
         M[i][NV] = frozen ? 0.0 : -gv[i];
@@ -656,10 +668,11 @@ __global__ __launch_bounds__(64) void k_equilibrium(const EqArgs a) {
       }
     }
     if (!improved) {   // no decrease at any damping: at round-off level of the residual, or at a constrained minimum
-      flag = 1;
+      flag = isfinite(cost) ? 1 : -1;
       break;
     }
   }
+  if (!isfinite(cost)) flag = -1;
   for (int k = 0; k < NV; ++k) {
     a.y[(size_t)k * B + b] = y[k];
     if (a.residual) a.residual[(size_t)k * B + b] = R[k];

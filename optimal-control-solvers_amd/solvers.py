@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, lib
+from ._lib import OcsError, check, lib
 from .control import PWLinearControl
 from .integrator import RK4Integrator, _dptr, _stream
 from .interp import vectorInterpolant
@@ -126,7 +126,9 @@ def compute_equilibrium(prob, xGuess, lamGuess, uGuess, lb, ub, r):
     dFdu_times_vec(0,x,u,[lam;1]) = 0 (:10-21), inside lb <= [x; lam; u] <= ub.  Solved on the device
     (ocs_compute_equilibrium: one thread per instance, projected Levenberg-Marquardt on the reference's residual;
     lsqnonlin is a MATLAB toolbox).  Guesses may carry a trailing batch dimension (nS x B, nS x B, nC x B): every
-    column is one instance (with the per-trajectory parameters of `prob`), and the outputs gain that dimension."""
+    column is one instance (with the per-trajectory parameters of `prob`), and the outputs gain that dimension.
+    exitflag: 1 converged, 0 iteration limit, -1 the residual is not finite (lsqnonlin errors there); a single
+    instance with exitflag -1 raises, a batch reports it per instance."""
     xG, lG, uG = (np.asarray(a, dtype=np.float64) for a in (xGuess, lamGuess, uGuess))
     batched = xG.ndim == 2
     nS, nC = prob.nS, prob.ControlBounds.shape[0]
@@ -141,8 +143,11 @@ def compute_equilibrium(prob, xGuess, lamGuess, uGuess, lb, ub, r):
     res = np.empty((n, B), order="F")
     resnorm = np.empty(B)
     flag = np.empty(B, dtype=np.int32)
-    check(lib.ocs_compute_equilibrium(prob._h, B, float(r), _p(yG), _p(lb), _p(ub), _p(y), _p(resnorm), _p(res),
-                                      flag.ctypes.data_as(C.POINTER(C.c_int))))
+    rc = lib.ocs_compute_equilibrium(prob._h, B, float(r), _p(yG), _p(lb), _p(ub), _p(y), _p(resnorm), _p(res),
+                                     flag.ctypes.data_as(C.POINTER(C.c_int)))
+    check(rc)
+    if rc > 0 and not batched:   # one instance: undefined values are an error, as in lsqnonlin
+        raise OcsError(rc, "compute_equilibrium: the residual of the optimality system is not finite at the guess")
     if batched:
         return y[:nS], y[nS:2 * nS], y[2 * nS:], resnorm, res, flag
     return y[:nS, 0], y[nS:2 * nS, 0], y[2 * nS:, 0], float(resnorm[0]), res[:, 0], int(flag[0])

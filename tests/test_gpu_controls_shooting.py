@@ -203,6 +203,32 @@ def _testoc_equilibrium(c, m, r):
     return x, 2 * c * u, u
 
 
+def test_compute_equilibrium_undefined_values_and_fixed_variables(ocs):
+    """compute_equilibrium.m:23-27: lsqnonlin raises an error on undefined values and never reports such a point as a
+    solution, and it accepts lb == ub.  Here: a guess with a NaN (or one that overflows the residual) gives exitflag -1
+    for that instance only; a single instance raises; a variable fixed by lb == ub stays put while the others solve the
+    remaining equations in the least-squares sense."""
+    prob = ocs.TestOCProblem(P, BOUNDS)
+    lb, ub = [0.0, -np.inf, 0.0], [np.inf, np.inf, 1.0]
+    xG = np.array([[2.7, np.nan, 2.7, 1e200]])
+    lG = np.array([[2.2, 2.2, np.nan, 2.2]])
+    uG = np.full((1, 4), 0.7)
+    xs, ls, us, resnorm, res, flag = ocs.compute_equilibrium(prob, xG, lG, uG, lb, ub, P["r"])
+    assert flag.tolist() == [1, -1, -1, -1] and resnorm[0] < 1e-24 and not np.isfinite(resnorm[1:]).any()
+    assert abs(xs[0, 0] - 2.7355691886341361) < 1e-12
+    with pytest.raises(ocs.OcsError):
+        ocs.compute_equilibrium(prob, np.nan, 2.2, 0.7, lb, ub, P["r"])
+    # u fixed at 0.5 by lb == ub: same point as with the active upper bound 0.5
+    xa, la, ua, rna, _, fa = ocs.compute_equilibrium(prob, 2.7, 2.2, 0.4, lb, [np.inf, np.inf, 0.5], P["r"])
+    xf, lf, uf, rnf, _, ff = ocs.compute_equilibrium(prob, 2.7, 2.2, 0.5, [0.0, -np.inf, 0.5], [np.inf, np.inf, 0.5], P["r"])
+    assert ff == 1 and uf[0] == 0.5 and np.isfinite(rnf)
+    assert abs(xf[0] - xa[0]) < 1e-9 and abs(lf[0] - la[0]) < 1e-9 and abs(rnf - rna) < 1e-12
+    # x fixed at its equilibrium value: the other two unknowns reach the root
+    xe = 2.7355691886341361
+    x1, l1, u1, rn1, _, f1 = ocs.compute_equilibrium(prob, xe, 2.0, 0.6, [xe, -np.inf, 0.0], [xe, np.inf, 1.0], P["r"])
+    assert f1 == 1 and x1[0] == xe and abs(l1[0] - 2.1701063402939477) < 1e-9 and abs(u1[0] - 0.72336878009798256) < 1e-9
+
+
 def test_compute_equilibrium_batched_on_device(ocs, oracle):
     """compute_equilibrium.m:10-27 as a batch: 4096 instances with per-instance c, every one against the analytic root
     and against the oracle-side residual; the device entry point; the reference's known answer from its guess."""
