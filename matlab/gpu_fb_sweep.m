@@ -18,6 +18,7 @@ function soln = gpu_fb_sweep(prob, x0, tspan, options)                         %
    x = zeros(nS, N+1);  lam = x;  uI = zeros(nC, o.nINTERP_PTS);  J = 0;  sweeps = int32(0);
    [rc, ~, ~, ~, ~, ~, ~, x, lam, uI, J, sweeps] = calllib('libocs', 'ocs_fb_sweep', integ.hnd.Value, ...
          prob.h.Value, 1, x0, o, [], [], x, lam, uI, J, sweeps, []);
+   if rc < 0, ocs_check(rc); end   % bad options, unsupported problem, HIP error; rc > 0 = OCS_NUM_NOT_CONVERGED:
    soln = struct();                                                            % stays empty (:77)
    if sweeps > 0
       interpPts = linspace(tspan(1), tspan(end), o.nINTERP_PTS);

@@ -293,11 +293,12 @@ static int sweep_problem(ocs_problem_s* p, ocs_problem_s** out) {
   *out = p;
   if (p->functor != Functor::LQ) return OCS_OK;
   if (p->pmask) return fail(OCS_ERR_UNSUPPORTED, "fb_sweep on the LQ problem: per-trajectory parameters are not supported");
-  if (!p->shadow || p->shadow_version != p->version) {
-    if (p->shadow) {
-      ocs_problem_destroy(p->shadow);
-      p->shadow = nullptr;
-    }
+  // Built once: the generated source depends on (nS, nC) only, and the parameter block and bounds of a registry problem
+  // never change after creation (a version bump of `p` comes from setting or clearing per-trajectory parameters, which
+  // this path rejects above) -- recompiling with hipRTC on every bump cost seconds for nS = 32.  The shadow has its own
+  // version (globally unique, ocs_handles.hpp next_version), which is what the integrator's cached tables are keyed on:
+  // a freed shadow's address may be reused, its version is not.
+  if (!p->shadow) {
     const std::string src = lq_plugin_source(p->nS, p->nC);
     ocs_problem q = nullptr;
     const int rc = ocs_problem_create_from_source(&q, src.c_str(), p->nS, p->nC, p->par.data(), (int)p->par.size(),

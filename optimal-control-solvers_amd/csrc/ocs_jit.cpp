@@ -81,15 +81,16 @@ static std::vector<std::string> kernel_names(int nS, bool rowsep) {
   n[UK_CONTROL_PTS] = "ocs::k_control_pts<ocs::UserP>";
   n[UK_TU_AT] = "ocs::k_tu_at<ocs::UserP>";
   n[UK_EQUILIBRIUM] = "ocs::k_equilibrium<ocs::UserP>";
+  const std::string wl = std::to_string(kScanW) + ", " + std::to_string(kScanL);
   if (rowsep) {   // (entries left empty are not compiled)
     n[UK_FWD_P2_X] = "ocs::k_forward_p2<ocs::UserP, true, true, false, 0>";
     n[UK_FWD_P2_J] = "ocs::k_forward_p2<ocs::UserP, false, true, false, 0>";
-    n[UK_SCAN_LAM_DJDU] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, true, false, 0>";
-    n[UK_SCAN_LAM] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, false, false, 0>";
-    n[UK_SCAN_DJDU] = "ocs::k_backward_scan<ocs::UserP, 16, 4, false, true, false, 0>";
-    n[UK_SCAN_LAM_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, true, true, 0>";
-    n[UK_SCAN_LAM_LT] = "ocs::k_backward_scan<ocs::UserP, 16, 4, true, false, true, 0>";
-    n[UK_SCAN_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, 16, 4, false, true, true, 0>";
+    n[UK_SCAN_LAM_DJDU] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", true, true, false, 0>";
+    n[UK_SCAN_LAM] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", true, false, false, 0>";
+    n[UK_SCAN_DJDU] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", false, true, false, 0>";
+    n[UK_SCAN_LAM_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", true, true, true, 0>";
+    n[UK_SCAN_LAM_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", true, false, true, 0>";
+    n[UK_SCAN_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", false, true, true, 0>";
   }
   return n;
 }

@@ -7,6 +7,12 @@
 
 namespace ocs {
 
+// Launch shapes shared by the registry launchers and the hipRTC instances of the same kernel templates (the name
+// strings of ocs_jit.cpp and the launch dimensions are derived from these; the launchers assert that they are the
+// kernel headers' own numbers)
+constexpr int kScanW = 16, kScanL = 4;   // k_backward_scan: waves per workgroup, steps per chunk
+constexpr int p2_waves(int nS) { return 4 + (nS == 4 ? 2 : 4); }   // k_forward_p2 without in-kernel control expansion
+
 enum UserKernel : int {
   UK_TCOEF = 0, UK_BUILD_REC, UK_FWD_X, UK_FWD_J, UK_FWD_UCONST, UK_BWD_LAM_DJDU, UK_BWD_LAM, UK_BWD_DJDU,
   UK_BWD_UCONST, UK_EVAL, UK_COSTATE, UK_CONTROL_GRID, UK_CONTROL_PTS, UK_TU_AT, UK_EQUILIBRIUM,

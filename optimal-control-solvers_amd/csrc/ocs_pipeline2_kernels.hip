@@ -52,7 +52,9 @@ int launch_forward_p2(const ProblemDesc& p, const GridDesc& g, int batch, const 
   if (!pipeline_problem_ok(p) || !pipeline_shape_ok(p.nS, g.N, batch, false)) return -1;
   if (p.functor == Functor::User) {   // the hipRTC instances of the same kernel template (generic row functions)
     const FwdArgsP2 au{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, frozen, ld, no_cost_row ? 1 : 0, gate};
-    const int TPW = 64 / p.nS, nwave = 4 + (p.nS == 4 ? 2 : 4);
+    static_assert(p2_waves(1) == P2Cfg<1>::NWAVE && p2_waves(2) == P2Cfg<2>::NWAVE && p2_waves(4) == P2Cfg<4>::NWAVE,
+                  "launch shape of the hipRTC instances");
+    const int TPW = 64 / p.nS, nwave = p2_waves(p.nS);
     void* args[] = {(void*)&au};
     return jit_launch(p.user, x ? UK_FWD_P2_X : UK_FWD_P2_J, dim3(batch / TPW), dim3(nwave * 64), args, s,
                       p.nS == 1 ? 0u : 48u * 1024u);

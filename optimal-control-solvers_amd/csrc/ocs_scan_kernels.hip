@@ -43,7 +43,6 @@ bool scan_problem_ok(const ProblemDesc& p) {
   return scan_supported(p.functor, p.nS, p.nC);
 }
 
-constexpr int kScanW = 16, kScanL = 4;
 
 template <class P>
 static void run_backward_scan(const BwdArgsScan& a, hipStream_t s) {

@@ -133,8 +133,9 @@ def test_row_separable_user_problem_on_the_fast_mappings(ocs, oracle, nS, N, bat
         outs[name] = (xd.cpu().numpy(), lamd.cpu().numpy(), dd.cpu().numpy())
     for a_, b_ in zip(outs["rows"], outs["registry"]):
         assert relerr(a_, b_) < 1e-12
+    # (reported, not asserted: a wall-clock bound on a shared GPU pool fails without a code defect; the steady-state
+    #  comparison is scripts/user_rows_time.py: 151 against 140 us)
     print(f"pass pair at batch 4096: registry {times['registry']*1e6:.1f} us, row functions {times['rows']*1e6:.1f} us")
-    assert times["rows"] < 1.25 * times["registry"]   # warm: 151 vs 140 us (scripts/user_rows_time.py)
 
 
 def test_row_separable_problem_whose_control_gradient_reads_the_state(ocs, oracle):
