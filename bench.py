@@ -110,14 +110,14 @@ def _sync():
     torch.cuda.synchronize()
 
 
-def fb_sweep_metric(ocs, dev, batch=16384, reps=5):
+def fb_sweep_metric(ocs, dev, batch=16384, reps=5, shard=True):
     """Second half of BASELINE.json's metric: fb_sweep iters/sec on configs[2] (SURVEY BL-3):
     TestOCProblem through the A9 adapter, T=10, N=1000 forward + 1000 backward, batch=16384 instances with
     x0 ~ U(0.5,2.5), c ~ U(1,2) (seed 20260402), u0 = lower bound, default tolerances, <= 50 sweeps.
     One iter = forward + costate + control update + convergence reduction for one instance; converged
     instances stop counting (the whole batch still runs until the last one is done).  Under world > 1 the instances
     shard into contiguous blocks (no exchange; the count of iterations is all-reduced)."""
-    world, rank, lo, hi = _shard(ocs, batch)
+    world, rank, lo, hi = _shard(ocs, batch) if shard else (1, 0, 0, batch)
     rng = np.random.default_rng(20260402)
     tspan = ocs.linspace(0.0, T_END, NSTEPS + 1)  # MATLAB's linspace, as fb_sweep.m:69-70 builds its point sets
     x0 = torch.tensor(np.ascontiguousarray(rng.uniform(0.5, 2.5, (1, batch))[:, lo:hi]), device=dev)
@@ -135,7 +135,7 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=5):
     sw = res["r"]["sweeps"].cpu().numpy()
     tot = torch.tensor([float(np.where(sw > 0, sw, 50).sum()), float((sw > 0).sum()), float(sw.max())],
                        dtype=torch.float64, device=dev)
-    if world > 1:
+    if shard and ocs.distributed.collectives_on():
         import torch.distributed as dist
         mx = tot[2:].clone()
         dist.all_reduce(tot[:2])
@@ -181,13 +181,27 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=5):
                          "frac_round1_definition": bytes_sweep_ref * bsps / 1e9 / HBM_PEAK_GBPS}}
 
 
-def bl4_metric(ocs, dev, batch=65536, reps=5):
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 peak, vector = matrix (public spec); the two share one datapath per SIMD
+                          # (scripts/probe/mfma_valu_overlap.hip), so this is the fp64 roofline whatever the mix
+
+
+def bl4_metric(ocs, dev, batch=65536, reps=5, shard=True):
     """BASELINE configs[3] (SURVEY BL-4): single_shooting objective + gradient (single_shooting.m:137-150) with a
     Chebyshev basis of 16 coefficients, TestOCProblem, N = 1000, batch = 65536 coefficient vectors (seed 20260403),
     sharded into contiguous blocks (8192 per GPU at 8 GPUs) through distributed.sharded_objective_eval: one evaluation
     = u = v*B, forward, adjoint, dJdv = dJdu*B' for the local block, then the all-gather of J, the best candidate and
-    the ensemble mean (the only collectives; KBs)."""
-    world, rank, lo, hi = _shard(ocs, batch)
+    the ensemble mean (the only collectives; KBs).  shard=False: the whole `batch` on this rank (the per-GPU shard of a
+    larger job, measured on one GPU).
+
+    Rooflines.  HBM: objective+gradient-only mode moves the checkpoint of every step once out and once in; SURVEY 8(d)
+    counts 8*2*nAug = 32 B per (trajectory, step) (this build checkpoints the state rows only: 16 B).  fp64: u and dJdu
+    never reach memory, so the pass is arithmetic: per (trajectory, step) the three products with the basis matrix
+    (expansion in both passes, contraction) are 3 * 2 samples * 2 nBasis = 192 flop; the RK4 state pass of TestOCProblem
+    52 flop (four F of 8 flop, RK4Integrator.m:39-48; the three stage states and the update of :50-51: 20); the discrete
+    adjoint with compute_dJdu 76 flop (four dFdx_times_vec of 7, :74-88; k1..k4 and the lam update: 26; four
+    dFdu_times_vec of 5 and the two column sums, :97-121: 22) -- the stage recomputation of this build is not counted:
+    320 flop."""
+    world, rank, lo, hi = _shard(ocs, batch) if shard else (1, 0, 0, batch)
     rng = np.random.default_rng(20260403)
     V = 0.05 * rng.normal(size=(16, batch)) / np.arange(1, 17)[:, None]
     V[0] += 0.5
@@ -207,28 +221,100 @@ def bl4_metric(ocs, dev, batch=65536, reps=5):
     Vl = Vg[:, lo:hi].contiguous()
 
     def one():
-        out["r"] = ocs.distributed.sharded_objective_eval(eval_local, Vg)
-    for _ in range(2):
+        out["r"] = ocs.distributed.sharded_objective_eval(eval_local, Vg) if shard else None
+    for _ in range(3):
+        eval_local(Vl)
         one()
     # `value`: the evaluations themselves (the data path), barrier-bracketed, max over ranks; the KB-size
     # post-reductions (J all-gather, best candidate, ensemble mean; each ends in a host read) are timed with them
     # once more and reported beside it
     dt = ocs.distributed.timed_max_over_ranks(lambda: eval_local(Vl), reps, _sync)
-    dt_red = ocs.distributed.timed_max_over_ranks(one, reps, _sync)
-    r = out["r"]
-    # objective+gradient-only mode: the checkpoint of every step is written once and read once, 8*2*nAug = 32 B
-    # per (trajectory, step); u and dJdu never reach memory (fused Chebyshev basis)
+    res = {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s inside objective+gradient evaluations",
+           "batch": batch, "batch_per_gpu": nloc, "n_basis": 16, "ms_per_batch_evaluation": dt * 1e3,
+           "evaluations_per_s": batch / dt, "finite": bool(torch.isfinite(G).all().item())}
+    if shard:
+        dt_red = ocs.distributed.timed_max_over_ranks(one, reps, _sync)
+        r = out["r"]
+        res.update({"ms_per_evaluation_with_post_reductions": dt_red * 1e3,
+                    "best_candidate": {"J": r["best"][0], "index": r["best"][1]}, "J_all_gathered": int(r["J_all"].numel())})
+    wave = nloc <= 32768 and nloc % 64 == 0
     bytes_eval = 32.0 * nloc * NSTEPS
-    return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s inside objective+gradient evaluations",
-            "batch": batch, "batch_per_gpu": nloc, "n_basis": 16, "ms_per_batch_evaluation": dt * 1e3,
-            "evaluations_per_s": batch / dt, "finite": bool(torch.isfinite(G).all().item()),
-            "ms_per_evaluation_with_post_reductions": dt_red * 1e3,
-            "best_candidate": {"J": r["best"][0], "index": r["best"][1]}, "J_all_gathered": int(r["J_all"].numel()),
-            "roofline": {"bound": "hbm (serial-chain bound at this batch: 1024 waves, one per SIMD)",
-                         "kernel": "k_forward_fc + k_backward_fc (fused Chebyshev basis), local block",
-                         "achieved": bytes_eval / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": bytes_eval / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None,
-                         "algorithmic_bytes_per_evaluation": bytes_eval}}
+    flops_eval = 320.0 * nloc * NSTEPS
+    tr = _replayed_traffic("bl4_traffic_latest.json", nloc)
+    res["roofline"] = {"bound": "mfma", "note": "fp64 arithmetic (vector + matrix instructions on one datapath): 320 flop per "
+                                                 "(trajectory, step), see the docstring",
+                       "kernel": ("k_forward_p2<NKS=4> + k_backward_fcs (wave-specialised state pass, adjoint scan, basis products "
+                                  "on v_mfma_f64_16x16x4_f64)" if wave else
+                                  "k_forward_fc + k_backward_fc (lane per trajectory, basis products as v_fmac_f64_dpp)") + ", local block",
+                       "achieved": flops_eval / dt / 1e12, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                       "frac": flops_eval / dt / 1e12 / FP64_PEAK_TFLOPS, "traffic": tr[0], "traffic_source": tr[1],
+                       "algorithmic_flops_per_evaluation": flops_eval}
+    res["roofline_hbm"] = {"bound": "hbm", "achieved": bytes_eval / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                           "frac": bytes_eval / dt / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_per_evaluation": bytes_eval}
+    return res
+
+
+def _replayed_traffic(name, nloc):
+    """HBM bytes per launch pair from a committed rocprofv3 PMC summary under profiles/ (replayed, not collected by this
+    run), if it was taken at this local batch."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", name)))
+        if tr.get("batch") == nloc:
+            return tr["hbm_bytes_per_evaluation"], f"{tr['source']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; replayed)"
+    except Exception:
+        pass
+    return None, None
+
+
+def pair_time(ocs, dev, nS, batch, reps=20, seed=20260410):
+    """ms per pass pair (compute_states + compute_adjoints, full output, automatic mapping) of the BL-2 problem family."""
+    tspan, x0_h, u_h = make_inputs(batch, dev, seed)
+    prob = ocs.LogisticProblem(M[:nS], C_PAR, R_PAR, [[0.0, 1.0]])
+    integ = ocs.RK4Integrator(tspan)
+    x0, u = torch.tensor(np.ascontiguousarray(x0_h[:nS]), device=dev), torch.tensor(u_h, device=dev)
+    x = torch.empty((NSTEPS + 1, nS + 1, batch), dtype=torch.float64, device=dev)
+    lam, dJdu = torch.empty_like(x), torch.empty_like(u)
+    J = torch.empty(batch, dtype=torch.float64, device=dev)
+
+    def pair():
+        integ.compute_states_dev(prob, x0, u, x, J)
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+    for _ in range(10):
+        pair()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        pair()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e3
+
+
+def strong_scaling_readiness(ocs, dev):
+    """The path has no exchange step, so the time of an N-GPU job is the one-GPU time at the shard size (plus a
+    latency-bound 8-byte all-reduce that overlaps the next step).  Measured here on ONE GPU: every BASELINE config at its
+    total size B and at its 8-GPU shard B / 8, the predicted strong-scaling efficiency at 8 GPUs  t(B) / (8 t(B / 8)),
+    and the BL-2 pass pair over batch 512 ... 65 536 (across the switches of the automatic mapping)."""
+    out = {"definition": "predicted_efficiency_8gpu = t(B) / (8 * t(B/8)), both measured on one GPU; the data path has no collective"}
+    sweep = {}
+    for b in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
+        sweep[str(b)] = pair_time(ocs, dev, NS, b, reps=20 if b <= 8192 else 8)
+    out["BL-2 pass pair ms by batch (LogisticK nS=4, N=1000, automatic mapping)"] = sweep
+    out["BL-2"] = {"B": 4096, "ms_B": sweep["4096"], "ms_shard": sweep["512"],
+                   "predicted_efficiency_8gpu": sweep["4096"] / (8 * sweep["512"])}
+    f_full, f_shard = fb_sweep_metric(ocs, dev, 16384, shard=False), fb_sweep_metric(ocs, dev, 2048, shard=False)
+    out["BL-3 fb_sweep"] = {"B": 16384, "ms_solve_B": f_full["seconds_per_solve"] * 1e3,
+                            "ms_solve_shard": f_shard["seconds_per_solve"] * 1e3,
+                            "batch_sweeps_per_s_shard": f_shard["batch_sweeps_per_s"],
+                            "predicted_efficiency_8gpu": f_full["seconds_per_solve"] / (8 * f_shard["seconds_per_solve"])}
+    b4f, b4s = bl4_metric(ocs, dev, 65536, shard=False), bl4_metric(ocs, dev, 8192, shard=False)
+    out["BL-4"] = {"B": 65536, "ms_B": b4f["ms_per_batch_evaluation"], "ms_shard": b4s["ms_per_batch_evaluation"],
+                   "predicted_efficiency_8gpu": b4f["ms_per_batch_evaluation"] / (8 * b4s["ms_per_batch_evaluation"]),
+                   "shard": b4s}
+    b5f, b5s = bl5_metric(ocs, dev, 8192, shard=False), bl5_metric(ocs, dev, 1024, shard=False)
+    out["BL-5"] = {"B": 8192, "ms_B": b5f["ms_pass_pair_max_over_ranks"], "ms_shard": b5s["ms_pass_pair_max_over_ranks"],
+                   "predicted_efficiency_8gpu": b5f["ms_pass_pair_max_over_ranks"] / (8 * b5s["ms_pass_pair_max_over_ranks"]),
+                   "shard_roofline": b5s["roofline"]}
+    return out
 
 
 def bl2_large_batch_metric(ocs, dev, batch=65536, reps=5):
@@ -293,17 +379,17 @@ def bl2_single_state_metric(ocs, dev, batch=4096, reps=50):
             "finite": bool(torch.isfinite(J).all().item())}
 
 
-FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X fp64 matrix peak (= fp64 vector peak), public spec
+FP64_MFMA_PEAK_TFLOPS = FP64_PEAK_TFLOPS
 
 
-def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2):
+def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2, shard=True):
     """BASELINE configs[4] (SURVEY BL-5): build-defined LQ32 (nS = 32, nC = 4, A = -diag(logspace(0,3,32)) + 0.1 G,
     seed 20260405), RK4InfiniteIntegrator with N2 = N = 4000 tail steps (|lambda_max| h = 2.5), uStar = 0,
     batch 8192 in total (sharded: 1024 per GPU at 8 GPUs -- 64 groups of 16 trajectories, i.e. 128 waves of the
     two-wave kernels on 1024 SIMDs: that leg is latency-bound by design of the config), full output.  The stage
     products A*Y / A'*k run on v_mfma_f64_16x16x4_f64 (csrc/ocs_lq_kernels.hip); fp64-compute-bound, so the roofline
     is the fp64 matrix peak."""
-    world, rank, lo, hi = _shard(ocs, batch)
+    world, rank, lo, hi = _shard(ocs, batch) if shard else (1, 0, 0, batch)
     nloc = hi - lo
     nS, nC, T = 32, 4, 10.0
     rng = np.random.default_rng(20260405)
@@ -378,7 +464,11 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
     import torch.distributed as dist
-    if world > 1:
+    # OCS_FORCE_COLLECTIVES=1 under torch.distributed.run with ONE process: the process group is created and every
+    # collective of the N-rank path (asynchronous objective all-reduce and its drain, barriers, max over ranks, the
+    # gathers of the secondary legs) executes on RCCL with world size 1 -- the rehearsal a one-GPU box allows
+    use_dist = world > 1 or (os.environ.get("OCS_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         torch.cuda.set_device(local_rank)
@@ -418,7 +508,7 @@ def main():
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
         if k is not None:
             ev[k][2].record()
-        if world > 1:
+        if use_dist:
             # the one collective of the path: all-reduce(SUM) of the objective over the shards, 8 bytes; issued
             # asynchronously on RCCL's stream so that its latency hides under the next step's kernels
             torch.sum(J, dim=0, keepdim=True, out=Jsums[i])
@@ -446,18 +536,18 @@ def main():
     drain()
     torch.cuda.synchronize()
     # (HIP event records between the kernels cost a few us of GPU idle time each, so the timed steps below carry none)
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
         one_step(k)
     drain()  # every step's objective sum has arrived before the clock stops
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -492,6 +582,7 @@ def main():
             "value": steps_total / dt,
             "unit": "steps/s",
             "n_gpus": world,
+            "collectives_executed": bool(use_dist),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
@@ -529,6 +620,7 @@ def main():
         b5 = bl5_metric(ocs, dev)
         big = bl2_large_batch_metric(ocs, dev) if world == 1 else None
         one = bl2_single_state_metric(ocs, dev) if world == 1 else None
+        ssr = strong_scaling_readiness(ocs, dev) if world == 1 and not use_dist else None
         if rank == 0:
             line["fb_sweep"] = fb
             line["other_configs"] = {"BL-4 chebyshev16 objective+gradient": b4,
@@ -537,6 +629,8 @@ def main():
                 line["other_configs"]["BL-2 problem at batch 65536 (lane mapping, HBM-bound regime)"] = big
             if one:
                 line["other_configs"]["BL-2 shapes with one state (TestOCProblem, nAug = 2)"] = one
+            if ssr:
+                line["other_configs"]["strong-scaling readiness (8-GPU shard sizes on one GPU)"] = ssr
     if rank == 0:
         if not args.no_cpu_baseline and world == 1:
             cb, ref = cpu_baseline(tspan, x0_h, u_h)
@@ -545,7 +639,7 @@ def main():
             err = float(np.max(np.abs(J.cpu().numpy() - ref["J"]) / np.maximum(1.0, np.abs(ref["J"]))))
             line["parity_J_max_rel_err_vs_oracle"] = err
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

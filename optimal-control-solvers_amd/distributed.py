@@ -7,6 +7,8 @@ batch is an ensemble whose mean objective is optimised, and an all-gather of per
 for best-candidate selection (RCCL has no MINLOC).  Works with any backend (tests use gloo on CPU)."""
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -25,6 +27,15 @@ def world_info():
     return 1, 0
 
 
+def collectives_on():
+    """Whether the post-reductions go through torch.distributed: a process group with more than one rank -- or, with
+    OCS_FORCE_COLLECTIVES=1, any initialised process group (one rank: every collective, barrier and the max-over-ranks
+    timing then execute as they would at N ranks; bench.py's rehearsal of the RCCL code path on a one-GPU box)."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return False
+    return dist.get_world_size() > 1 or os.environ.get("OCS_FORCE_COLLECTIVES") == "1"
+
+
 def ensemble_objective(J_local: torch.Tensor, dJdv_local: torch.Tensor | None = None):
     """Mean objective (and mean gradient) of the global ensemble from each rank's shard.
     J_local [B_loc], dJdv_local [nV][B_loc].  One all-reduce of 2 + nV doubles."""
@@ -34,8 +45,7 @@ def ensemble_objective(J_local: torch.Tensor, dJdv_local: torch.Tensor | None = 
     buf[1] = float(J_local.numel())
     if nV:
         buf[2:] = dJdv_local.sum(dim=1)
-    world, _ = world_info()
-    if world > 1:
+    if collectives_on():
         dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     Jmean = buf[0] / buf[1]
     return (Jmean, None) if not nV else (Jmean, buf[2:] / buf[1])
@@ -46,7 +56,7 @@ def best_candidate(J_local: torch.Tensor, lo: int):
     jmin, imin = torch.min(J_local, dim=0)
     pair = torch.stack([jmin.to(torch.float64), (imin + lo).to(torch.float64)])
     world, _ = world_info()
-    if world == 1:
+    if not collectives_on():
         return float(pair[0]), int(pair[1])
     gathered = [torch.empty_like(pair) for _ in range(world)]
     dist.all_gather(gathered, pair)
@@ -59,7 +69,7 @@ def gather_objectives(J_local: torch.Tensor, total: int):
     """All-gather of the full J vector (BL-4: 64 KB per rank).  Shards may differ by one element, so
     each rank pads to the largest shard."""
     world, rank = world_info()
-    if world == 1:
+    if not collectives_on():
         return J_local.clone()
     sizes = [shard_bounds(total, world, r) for r in range(world)]
     mx = max(h - l for l, h in sizes)
@@ -95,20 +105,20 @@ def timed_max_over_ranks(fn, reps: int, sync=None):
     """Wall time of `reps` calls of fn(), bracketed by a barrier and `sync()` on both sides, maximum over ranks
     (the contract bench.py's headline loop follows)."""
     import time
-    world, _ = world_info()
+    on = collectives_on()
     if sync:
         sync()
-    if world > 1:
+    if on:
         dist.barrier()
     t0 = time.perf_counter()
     for _ in range(reps):
         fn()
     if sync:
         sync()
-    if world > 1:
+    if on:
         dist.barrier()
     dt = time.perf_counter() - t0
-    if world > 1:
+    if on:
         t = torch.tensor([dt], dtype=torch.float64, device=_reduce_device())
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
