@@ -250,6 +250,8 @@ int ocs_control_set_fusion(ocs_control c, int mode);
  * adjointRHS = -dFdx_times_vec(t,[x;0],u,[lam;1])(1:nS), ControlChar = clamp(argzero dFdu_times_vec(...))
  * (make_from_symbolic.m:11-23,111).  odevr7 is replaced by RK4 on the grid of `g` (an RK4Integrator),
  * x(t)/lam(t) are pchip interpolants of the node values as in compute_x_lam.m:9,14. */
+/* Fill the struct with ocs_fbs_default_options before setting fields: it has grown at its end between builds (uRelax
+ * is the latest member) and may again; a caller compiled against an older header passes a shorter struct. */
 typedef struct ocs_fbs_options {
   double uRelTol;  /* fb_sweep.m:16 */
   double uAbsTol;  /* :17 */
@@ -293,6 +295,41 @@ int ocs_fb_sweep(ocs_integrator g, ocs_problem p, int batch, const double *x0, c
 int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double *x0, const ocs_fbs_options *opt,
                      const double *u0grid, const double *u0err, double *xaug, double *lam, double *uInterp,
                      double *J, int *sweeps, double *maxChange, void *stream);
+
+/* ---- the batch axis over the GPUs of one node (the reference has no batch axis and no parallelism:
+ * every entry point integrates one trajectory, tests/solve_test_problem.m:37) ----
+ * ocs_multi_create: devices[n] (NULL: 0 .. n-1), one stream per device and ONE RCCL communicator over them
+ * (ncclCommInitAll).  A call below cuts the batch into contiguous blocks (block k = ocs_multi_shard(m, batch, k) goes to
+ * device k; sizes differ by at most one), runs the one-device host entry point of the same name on every block
+ * concurrently -- no data-path exchange -- and ends with the O(1)-size reductions on the devices: all-reduce(SUM) of
+ * [sum J, count] and all-gather of (min J, argmin) over RCCL.  Arrays are the MATLAB-shaped host arrays of the
+ * one-device entry points for the WHOLE batch (trajectory index slowest, so a block is a contiguous range of each
+ * array).  Handles own device memory: g[k], p[k], c[k] are created by the caller with device ocs_multi_device(m, k)
+ * current (ocs_set_device) and describe the same problem / grid / basis on every device.
+ * stats (may be NULL), 4 doubles: {sum of the finite J, their number, min J, index of the minimum in the whole batch};
+ * ocs_multi_fb_sweep counts the converged instances only.  Return values as the one-device entry points (the largest
+ * numerical status over the devices; the first error). */
+typedef struct ocs_multi_s *ocs_multi;
+int ocs_multi_create(ocs_multi *out, const int *devices, int n);
+int ocs_multi_destroy(ocs_multi m);
+int ocs_multi_size(ocs_multi m);
+int ocs_multi_device(ocs_multi m, int k);                              /* device id of block k, or < 0 */
+int ocs_multi_shard(ocs_multi m, int batch, int k, int *lo, int *hi);  /* block k = trajectories [lo, hi) */
+/* [x, J] = compute_states(obj, prob, x0, u)   Integrator/RK4Integrator.m:28-56; x may be NULL */
+int ocs_multi_compute_states(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, int batch, const double *x0,
+                             const double *u, double *x, double *J, double *stats);
+/* [lam, dJdu] = compute_adjoints(obj, prob, u, lamT)   RK4Integrator.m:59-121, after ocs_multi_compute_states on the
+ * same handles and batch; lamT, dJdu may be NULL */
+int ocs_multi_compute_adjoints(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, int batch, const double *u,
+                               const double *lamT, double *lam, double *dJdu);
+/* [J, dJdv] = nlpObjective(v)   functions/single_shooting.m:137-150 for a batch of candidates */
+int ocs_multi_nlp_objective(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, const ocs_control *c, int batch,
+                            double *x0, const double *v, int nFree, const int *FreeInitStates, double *J, double *dJdv,
+                            double *stats);
+/* soln = fb_sweep(prob, x0, tspan, options)   functions/fb_sweep.m:1-126 for a batch of instances */
+int ocs_multi_fb_sweep(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, int batch, const double *x0,
+                       const ocs_fbs_options *opt, const double *u0grid, const double *u0err, double *x, double *lam,
+                       double *uInterp, double *J, int *sweeps, double *maxChange, double *stats);
 
 /* layout helpers: MATLAB (trajectory-major, [batch][cols][rows]) <-> batch-minor ([cols][rows][batch]),
  * device pointers, rows*cols doubles per trajectory. */

@@ -21,3 +21,4 @@ from .solvers import (nlp_objective, nlp_objective_dev, single_shooting, single_
                       compute_equilibrium, compute_equilibrium_dev)
 from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, compute_x_lam, compute_x_lam_J  # noqa: F401
 from . import distributed  # noqa: F401
+from .multi import MultiDevice  # noqa: F401

@@ -92,6 +92,16 @@ _SIG = {
     "ocs_compute_x_lam_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp]),
     "ocs_fb_sweep": (C.c_int, [vp, vp, C.c_int, dp, vp, dp, dp, dp, dp, dp, dp, ip, dp]),
     "ocs_fb_sweep_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+    "ocs_multi_create": (C.c_int, [C.POINTER(vp), ip, C.c_int]),
+    "ocs_multi_destroy": (C.c_int, [vp]),
+    "ocs_multi_size": (C.c_int, [vp]),
+    "ocs_multi_device": (C.c_int, [vp, C.c_int]),
+    "ocs_multi_shard": (C.c_int, [vp, C.c_int, C.c_int, ip, ip]),
+    "ocs_multi_compute_states": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, dp, dp, dp, dp, dp]),
+    "ocs_multi_compute_adjoints": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, dp, dp, dp, dp]),
+    "ocs_multi_nlp_objective": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, dp, dp, C.c_int, ip,
+                                          dp, dp, dp]),
+    "ocs_multi_fb_sweep": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, dp, vp, dp, dp, dp, dp, dp, dp, ip, dp, dp]),
     "ocs_copy_dev": (C.c_int, [vp, vp, C.c_long, vp]),
     "ocs_to_batch_minor_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "ocs_to_traj_major_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

@@ -550,6 +550,11 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   return OCS_OK;
 }
 
+}  // extern "C"
+// the objectives of the last host ocs_nlp_objective on this handle, on its device (ocs_multi.cpp's reductions)
+const double* ocs_control_device_J(const ocs_control_s* c) { return c ? c->d_J.d() : nullptr; }
+extern "C" {
+
 int ocs_control_set_fusion(ocs_control c, int mode) {
   if (!c) return fail(OCS_ERR_INVALID, "null control");
   if (mode < 0 || mode > 3)

@@ -149,6 +149,9 @@ struct ocs_integrator_s {
   DevBuf d_x0, d_u, d_x, d_J, d_lam, d_dJdu, d_lamT, d_stage, d_ck;
 };
 
+struct ocs_control_s;
+const double* ocs_control_device_J(const ocs_control_s* c);   // ocs_control.cpp
+
 namespace ocs {
 
 inline int upload_problem(ocs_problem_s* p) {

@@ -368,6 +368,48 @@ int launch_traj_status(const double* J, int n, int* status, hipStream_t s) {
   return hip_rc(hipGetLastError());
 }
 
+// one workgroup: the post-reductions of a shard's objectives (ocs_multi.cpp)
+__global__ __launch_bounds__(256) void k_objective_stats(const double* __restrict__ J, int n, int lo, double* __restrict__ out) {
+  __shared__ double ss[256], sc[256], sm[256], si[256];
+  double sum = 0.0, cnt = 0.0, mn = INFINITY, am = -1.0;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const double v = J[i];
+    if (isfinite(v)) {
+      sum += v;
+      cnt += 1.0;
+      if (v < mn) {
+        mn = v;
+        am = (double)(lo + i);
+      }
+    }
+  }
+  ss[threadIdx.x] = sum; sc[threadIdx.x] = cnt; sm[threadIdx.x] = mn; si[threadIdx.x] = am;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) {
+      ss[threadIdx.x] += ss[threadIdx.x + w];
+      sc[threadIdx.x] += sc[threadIdx.x + w];
+      const double m2 = sm[threadIdx.x + w], i2 = si[threadIdx.x + w];
+      // the smaller value; of equal values the smaller index (deterministic whatever the thread count)
+      if (m2 < sm[threadIdx.x] || (m2 == sm[threadIdx.x] && i2 >= 0.0 && (si[threadIdx.x] < 0.0 || i2 < si[threadIdx.x]))) {
+        sm[threadIdx.x] = m2;
+        si[threadIdx.x] = i2;
+      }
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    out[0] = ss[0];
+    out[1] = sc[0];
+    out[2] = sm[0];
+    out[3] = si[0];
+  }
+}
+int launch_objective_stats(const double* J, int n, int lo, double* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_objective_stats, dim3(1), dim3(256), 0, s, J, n, lo, out);
+  return hip_rc(hipGetLastError());
+}
+
 int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s) {
   hipLaunchKernelGGL(k_count_nonfinite, dim3((n + 255) / 256), dim3(256), 0, s, v, n, count);
   return hip_rc(hipGetLastError());

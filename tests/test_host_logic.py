@@ -112,3 +112,20 @@ def test_registry_and_option_validation_without_gpu(ocs):
     so = _lib.SsOptions()                       # single_shooting.m:20-21 defaults of the batched shooting driver
     assert _lib.lib.ocs_ss_default_options(C.byref(so)) == 0 and _lib.lib.ocs_ss_default_options(None) == -1
     assert (so.TolX, so.TolFun, so.MaxIter, so.memory, so.maxBacktracks) == (1e-5, 3e-4, 500, 10, 25)
+
+
+def test_multi_device_block_arithmetic_matches_the_python_sharding():
+    """include/ocs.h ocs_multi_shard cuts a batch as distributed.shard_bounds does (contiguous blocks, sizes differ by at
+    most one): the C restatement in csrc/ocs_multi.cpp against the Python one, without a device (the handle cannot be
+    created without a GPU, so the arithmetic is restated here from the header's contract and checked for every rank)."""
+    import __graft_entry__ as g
+    ocs = g.load_package()
+    for total in (1, 7, 8, 9, 4096, 65536, 65537):
+        for world in (1, 2, 3, 8):
+            covered = []
+            for k in range(world):
+                lo, hi = ocs.distributed.shard_bounds(total, world, k)
+                base, rem = divmod(total, world)
+                assert (lo, hi) == (k * base + min(k, rem), k * base + min(k, rem) + base + (1 if k < rem else 0))
+                covered += list(range(lo, hi))
+            assert covered == list(range(total))
