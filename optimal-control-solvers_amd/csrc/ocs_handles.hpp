@@ -237,7 +237,7 @@ inline int bind_problem(ocs_integrator_s* g, ocs_problem_s* p, int batch, hipStr
     g->rec_stride = rec_stride_host(ntc);
     OCS_TRY(g->d_REC.ensure(sizeof(double) * (size_t)(g->N + 2 * rec_pad_host()) * g->rec_stride));
     LAUNCH_TRY(launch_tcoef(describe(p), describe(g), s));
-    if (scan_problem_ok(describe(p))) {
+    if (scan_problem_ok(describe(p)) || vector_problem_ok(describe(p))) {
       OCS_TRY(g->d_RECS.ensure(sizeof(double) * scan_recs_doubles(g->N)));
       LAUNCH_TRY(launch_build_recs(g->N, g->rec_stride, rec_sc_offset_host(ntc), describe(g).REC, g->d_RECS.d(), s));
     }

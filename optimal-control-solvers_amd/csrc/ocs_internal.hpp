@@ -45,6 +45,16 @@ bool scan_supported(Functor f, int nS, int nC);
 bool user_rowsep(const UserModule* m);
 bool scan_problem_ok(const ProblemDesc& p);
 bool pipeline_problem_ok(const ProblemDesc& p);
+// any OCProblem with nS <= 4, nC <= 2 (coupled rows, several controls): the vector-lane state pass
+// (ocs_pipelinev_kernel.hpp; whole blocks of 8 steps, whole tiles of 64 trajectories) and the scan adjoint pass with
+// dense step maps (ocs_vscan_kernel.hpp; N a multiple of scan_chunk_steps())
+bool user_vector(const UserModule* m);
+bool vector_problem_ok(const ProblemDesc& p);
+int launch_forward_pv(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u, double* x,
+                      double* J, hipStream_t s, bool no_cost_row, const int* gate);
+int launch_backward_vscan(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                          const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
+                          hipStream_t s);
 // N a multiple of scan_chunk_steps(); pend0 as for launch_backward_pl
 int scan_chunk_steps();
 int launch_backward_scan(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,

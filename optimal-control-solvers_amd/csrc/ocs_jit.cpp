@@ -63,7 +63,7 @@ static Rtc* rtc() {
 
 int user_chunk(int nS) { return nS <= 4 ? 4 : 1; }
 
-static std::vector<std::string> kernel_names(int nS, bool rowsep) {
+static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep) {
   const std::string ch = std::to_string(user_chunk(nS));
   std::vector<std::string> n(UK_COUNT);
   n[UK_TCOEF] = "ocs::k_tcoef<ocs::UserP>";
@@ -92,6 +92,17 @@ static std::vector<std::string> kernel_names(int nS, bool rowsep) {
     n[UK_SCAN_LAM_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", true, false, true, 0>";
     n[UK_SCAN_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", false, true, true, 0>";
   }
+  if (!rowsep && vector_shape_ok(nS, nC)) {
+    const std::string vw = std::to_string(vscan_waves(nS)) + ", " + std::to_string(kVScanL);
+    n[UK_FWD_PV_X] = "ocs::k_forward_pv<ocs::UserP, true>";
+    n[UK_FWD_PV_J] = "ocs::k_forward_pv<ocs::UserP, false>";
+    n[UK_VSCAN_LAM_DJDU] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", true, true, false>";
+    n[UK_VSCAN_LAM] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", true, false, false>";
+    n[UK_VSCAN_DJDU] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", false, true, false>";
+    n[UK_VSCAN_LAM_DJDU_LT] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", true, true, true>";
+    n[UK_VSCAN_LAM_LT] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", true, false, true>";
+    n[UK_VSCAN_DJDU_LT] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", false, true, true>";
+  }
   return n;
 }
 
@@ -116,17 +127,21 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   src += user_src;
   src += "\n#include \"ocs_user_functor.hpp\"\n#include \"ocs_rk4_kernels.hpp\"\n#include \"ocs_fbs_device.hpp\"\n";
   if (rowsep) src += "#include \"ocs_pipeline2_kernel.hpp\"\n#include \"ocs_scan_kernel.hpp\"\n";
+  const bool vec = !rowsep && vector_shape_ok(nS, nC);
+  if (vec) src += "#include \"ocs_pipelinev_kernel.hpp\"\n#include \"ocs_vscan_kernel.hpp\"\n";
 
   const char* hdr_src[] = {src_ocs_device_common_hpp, src_ocs_user_functor_hpp, src_ocs_rk4_kernels_hpp,
-                           src_ocs_fbs_device_hpp, src_ocs_pipeline2_kernel_hpp, src_ocs_scan_kernel_hpp};
+                           src_ocs_fbs_device_hpp, src_ocs_pipeline2_kernel_hpp, src_ocs_scan_kernel_hpp,
+                           src_ocs_pipelinev_kernel_hpp, src_ocs_vscan_kernel_hpp};
   const char* hdr_name[] = {"ocs_device_common.hpp", "ocs_user_functor.hpp", "ocs_rk4_kernels.hpp",
-                            "ocs_fbs_device.hpp", "ocs_pipeline2_kernel.hpp", "ocs_scan_kernel.hpp"};
+                            "ocs_fbs_device.hpp", "ocs_pipeline2_kernel.hpp", "ocs_scan_kernel.hpp",
+                            "ocs_pipelinev_kernel.hpp", "ocs_vscan_kernel.hpp"};
   hiprtcProgram prog = nullptr;
-  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 6, hdr_src, hdr_name) != 0) {
+  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 8, hdr_src, hdr_name) != 0) {
     log = "hiprtcCreateProgram failed";
     return OCS_ERR_HIP;
   }
-  const std::vector<std::string> names = kernel_names(nS, rowsep);
+  const std::vector<std::string> names = kernel_names(nS, nC, rowsep);
   for (const std::string& n : names)
     if (!n.empty()) r->AddNameExpression(prog, n.c_str());
   // The include directory of the ROCm installation explicitly: hipRTC normally serves <hip/hip_runtime.h> from a built-in
@@ -154,6 +169,7 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   m->npar = npar;
   m->has_cc = has_cc;
   m->rowsep = rowsep;
+  m->vector = vec;
   m->chunk = user_chunk(nS);
   std::vector<std::string> lowered(UK_COUNT);
   for (int k = 0; k < UK_COUNT; ++k) {
@@ -197,6 +213,7 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
 }
 
 bool user_rowsep(const UserModule* m) { return m && m->rowsep; }
+bool user_vector(const UserModule* m) { return m && m->vector; }
 
 void jit_free(UserModule* m) {
   if (!m) return;

@@ -12,18 +12,25 @@ namespace ocs {
 // kernel headers' own numbers)
 constexpr int kScanW = 16, kScanL = 4;   // k_backward_scan: waves per workgroup, steps per chunk
 constexpr int p2_waves(int nS) { return 4 + (nS == 4 ? 2 : 4); }   // k_forward_p2 without in-kernel control expansion
+constexpr int kPvWaves = 7;                                          // k_forward_pv: M, S, C x 4, J
+constexpr int vscan_waves(int nS) { return nS == 1 ? 16 : (nS * nS + nS <= 12 ? 8 : 4); }   // k_backward_vscan
+constexpr int kVScanL = 4;
+constexpr bool vector_shape_ok(int nS, int nC) { return nS >= 1 && nS <= 4 && nC >= 1 && nC <= 2; }
 
 enum UserKernel : int {
   UK_TCOEF = 0, UK_BUILD_REC, UK_FWD_X, UK_FWD_J, UK_FWD_UCONST, UK_BWD_LAM_DJDU, UK_BWD_LAM, UK_BWD_DJDU,
   UK_BWD_UCONST, UK_EVAL, UK_COSTATE, UK_CONTROL_GRID, UK_CONTROL_PTS, UK_TU_AT, UK_EQUILIBRIUM,
   // row-separable user problems only (OCS_USER_ROWSEP): the wave-specialised state pass and the scan adjoint pass
   UK_FWD_P2_X, UK_FWD_P2_J, UK_SCAN_LAM_DJDU, UK_SCAN_LAM, UK_SCAN_DJDU, UK_SCAN_LAM_DJDU_LT, UK_SCAN_LAM_LT, UK_SCAN_DJDU_LT,
+  // problems given as the three full-vector methods (coupled rows, several controls), nS <= 4, nC <= 2: the vector-lane
+  // state pass (ocs_pipelinev_kernel.hpp) and the scan adjoint pass with dense step maps (ocs_vscan_kernel.hpp)
+  UK_FWD_PV_X, UK_FWD_PV_J, UK_VSCAN_LAM_DJDU, UK_VSCAN_LAM, UK_VSCAN_DJDU, UK_VSCAN_LAM_DJDU_LT, UK_VSCAN_LAM_LT, UK_VSCAN_DJDU_LT,
   UK_COUNT
 };
 
 struct UserModule {
   int nS = 0, nC = 0, npar = 0, chunk = 4;
-  bool has_cc = false, loaded = false, rowsep = false;
+  bool has_cc = false, loaded = false, rowsep = false, vector = false;
   std::vector<char> code;
   hipModule_t mod = nullptr;
   hipFunction_t fn[UK_COUNT] = {};

@@ -158,16 +158,22 @@ static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
 static int pipeline_steps(const ProblemDesc& p, int N, int batch, bool backward) {
   const int D = pipeline_block_steps(), N1 = (N / D) * D;
   // (user problems given as row functions have the state-pass kernel only: their adjoint pass is the scan)
-  if (backward ? !pipeline_supported(p.functor, p.nS, p.nC) : !pipeline_problem_ok(p)) return 0;
+  if (backward ? !pipeline_supported(p.functor, p.nS, p.nC) : !pipeline_problem_ok(p)) {
+    // any other problem with nS <= 4, nC <= 2: the vector-lane state pass (whole tiles of 64 trajectories)
+    if (!backward && vector_problem_ok(p) && N1 >= D && batch >= 64 && batch % 64 == 0) return N1;
+    return 0;
+  }
   if (N1 < D || !pipeline_shape_ok(p.nS, N1, batch, backward)) return 0;
   return N1;
 }
+static bool forward_is_vector(const ProblemDesc& p) { return !pipeline_problem_ok(p) && vector_problem_ok(p); }
 // boundary: the caller's output arrays can carry the hand-over column of a split pass (x forward, lam backward)
 static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested, bool plain, bool backward,
                           bool boundary) {
   if (requested != MAP_AUTO) return requested;
   const int N1 = plain ? pipeline_steps(p, N, batch, backward) : 0;
-  if (N1 > 0 && (N1 == N || boundary) && batch / (64 / p.nS) <= 512) return MAP_PIPELINE;
+  const int tpw = (!backward && forward_is_vector(p)) ? 64 : 64 / p.nS;
+  if (N1 > 0 && (N1 == N || boundary) && batch / tpw <= 512) return MAP_PIPELINE;
   if (plain && rowsplit_supported(p.functor, p.nS, p.nC) && batch <= 8192) return MAP_ROWSPLIT;
   return MAP_LANE;
 }
@@ -193,13 +199,20 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
   // (MAP_SCAN names the adjoint kernel; the state pass of such an integrator is chosen automatically)
   int map = choose_mapping(p, g.N, batch, o.mapping == MAP_SCAN ? MAP_AUTO : o.mapping, plain, false, x != nullptr);
   if (map == MAP_ROWSPLIT && (o.frozen || o.ld) && o.mapping == MAP_AUTO) map = MAP_LANE;  // not in that kernel
+  if (map == MAP_PIPELINE && forward_is_vector(p) && (o.frozen || o.ld) && o.mapping == MAP_AUTO) map = MAP_LANE;
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, false) : 0;
     if (N1 == 0 || (N1 < g.N && !x)) return -1;  // the split needs the boundary column in memory
     GridDesc g1 = g;
     g1.N = N1;
     // (a split pass hands the running objective to the lane kernel through the boundary column: keep the row then)
-    int rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s, o.no_cost_row && N1 == g.N, o.gate);
+    int rc;
+    if (forward_is_vector(p)) {
+      if (o.frozen || o.ld) return -1;
+      rc = launch_forward_pv(p, g1, batch, x0, u, x, J, s, o.no_cost_row && N1 == g.N, o.gate);
+    } else {
+      rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s, o.no_cost_row && N1 == g.N, o.gate);
+    }
     if (rc || N1 == g.N) return rc;
     // remaining steps N1 .. N-1 on the lane kernel, continuing from column N1 (state rows and running objective)
     const size_t ldb = o.ld ? o.ld : batch;
@@ -255,9 +268,17 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
   const int Ls = scan_chunk_steps(), Ns = (g.N / Ls) * Ls;
   const bool scan_ok = plain && g.RECS && scan_problem_ok(p) && Ns >= Ls && (Ns == g.N || lam || o.split_scratch);
   if (o.mapping == MAP_AUTO && scan_ok && scan_pays(p.nS, g.N, batch)) map = MAP_SCAN;
+  // any other problem with nS <= 4, nC <= 2: the scan with dense step maps, while the lane kernel would leave most of
+  // the chip idle (it does (nS + 2) times the arithmetic of a serial step)
+  const bool vscan = !scan_ok && plain && g.RECS && vector_problem_ok(p) && Ns >= Ls && (Ns == g.N || lam || o.split_scratch);
+  if (o.mapping == MAP_AUTO && vscan && g.N >= 8 && batch <= 16384 * 3 / (p.nS + 2)) map = MAP_SCAN;
+  auto scan_launch = [&](const GridDesc& gg, const double* lT, const double* pend0) {
+    return vscan ? launch_backward_vscan(p, gg, batch, xck, u, lT, lam, dJdu, o.lam0, pend0, s)
+                 : launch_backward_scan(p, gg, batch, xck, u, lT, lam, dJdu, o.lam0, pend0, s);
+  };
   if (map == MAP_SCAN) {
-    if (!scan_ok) return -1;
-    if (Ns == g.N) return launch_backward_scan(p, g, batch, xck, u, lamT, lam, dJdu, o.lam0, nullptr, s);
+    if (!scan_ok && !vscan) return -1;
+    if (Ns == g.N) return scan_launch(g, lamT, nullptr);
     const size_t col = (size_t)(p.nS + 1) * batch, ucol = (size_t)p.nC * batch;
     double* lamb = lam ? lam + (size_t)Ns * col : o.split_scratch;   // lam(:, Ns): in the output array, or as lam0
     double* db = dJdu ? dJdu + (size_t)(2 * Ns) * ucol : nullptr;
@@ -276,7 +297,7 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
     if (rc) return rc;
     GridDesc g1 = g;
     g1.N = Ns;
-    return launch_backward_scan(p, g1, batch, xck, u, lamb, lam, dJdu, o.lam0, db, s);
+    return scan_launch(g1, lamb, db);
   }
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, true) : 0;

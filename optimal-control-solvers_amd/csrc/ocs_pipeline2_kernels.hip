@@ -1,6 +1,7 @@
 // ocs_pipeline2_kernels.hip -- launchers of the state-pass kernel k_forward_p2 (ocs_pipeline2_kernel.hpp) for the
 // registry problems and the dispatch to the hipRTC instances of user problems given as row functions.
 #include "ocs_pipeline2_kernel.hpp"
+#include "ocs_pipelinev_kernel.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_jit.hpp"
 #include "ocs_problems.hpp"
@@ -17,6 +18,37 @@ bool pipeline_shape_ok(int nS, int N, int batch, bool backward);
 bool pipeline_problem_ok(const ProblemDesc& p) {
   if (p.functor == Functor::User) return user_rowsep(p.user) && (p.nS == 1 || p.nS == 2 || p.nS == 4) && p.nC == 1;
   return pipeline_supported(p.functor, p.nS, p.nC);
+}
+
+bool vector_problem_ok(const ProblemDesc& p) {
+  if (!vector_shape_ok(p.nS, p.nC)) return false;
+  if (p.functor == Functor::User) return user_vector(p.user);
+  return p.functor == Functor::Logistic;
+}
+template <class P>
+static void run_forward_pv(const FwdArgsP2& a, hipStream_t s) {
+  static_assert(PVCfg<P::NS, P::NC>::NWAVE == kPvWaves, "launch shape of the hipRTC instances");
+  const dim3 grid(a.batch / 64), block(kPvWaves * 64);
+  if (a.x)
+    k_forward_pv<P, true><<<grid, block, 0, s>>>(a);
+  else
+    k_forward_pv<P, false><<<grid, block, 0, s>>>(a);
+}
+int launch_forward_pv(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u, double* x,
+                      double* J, hipStream_t s, bool no_cost_row, const int* gate) {
+  if (!vector_problem_ok(p) || g.N < 8 || g.N % 8 != 0 || batch < 64 || batch % 64 != 0) return -1;
+  const FwdArgsP2 a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, 0, no_cost_row ? 1 : 0, gate};
+  if (p.functor == Functor::User) {
+    void* args[] = {(void*)&a};
+    return jit_launch(p.user, x ? UK_FWD_PV_X : UK_FWD_PV_J, dim3(batch / 64), dim3(kPvWaves * 64), args, s);
+  }
+  switch (p.nS) {
+    case 1: run_forward_pv<LogisticK<1>>(a, s); break;
+    case 2: run_forward_pv<LogisticK<2>>(a, s); break;
+    case 3: run_forward_pv<LogisticK<3>>(a, s); break;
+    default: run_forward_pv<LogisticK<4>>(a, s); break;
+  }
+  return hip_rc7(hipGetLastError());
 }
 
 template <class P, bool UNI>

@@ -1,6 +1,7 @@
 // ocs_scan_kernels.hip -- launchers of the scan adjoint kernel (ocs_scan_kernel.hpp) for the registry problems, its
 // record table, and the dispatch to the hipRTC instances of user problems given as row functions.
 #include "ocs_scan_kernel.hpp"
+#include "ocs_vscan_kernel.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_jit.hpp"
 #include "ocs_problems.hpp"
@@ -70,6 +71,46 @@ static void run_backward_scan(const BwdArgsScan& a, hipStream_t s) {
   } else {
     k_backward_scan<P, kScanW, kScanL, false, true, false><<<grid, block, 0, s>>>(a);
   }
+}
+
+template <class P>
+static void run_backward_vscan(const BwdArgsScan& a, hipStream_t s) {
+  constexpr int W = VScanCfg<P::NS>::W, L = VScanCfg<P::NS>::L;
+  static_assert(W == vscan_waves(P::NS) && L == kVScanL && L == kScanL, "launch shape of the hipRTC instances");
+  const dim3 grid((a.batch + 63) / 64), block(W * 64);
+  if (a.lamT) {
+    if (a.lam && a.dJdu)
+      k_backward_vscan<P, W, L, true, true, true><<<grid, block, 0, s>>>(a);
+    else if (a.lam)
+      k_backward_vscan<P, W, L, true, false, true><<<grid, block, 0, s>>>(a);
+    else
+      k_backward_vscan<P, W, L, false, true, true><<<grid, block, 0, s>>>(a);
+  } else if (a.lam && a.dJdu) {
+    k_backward_vscan<P, W, L, true, true, false><<<grid, block, 0, s>>>(a);
+  } else if (a.lam) {
+    k_backward_vscan<P, W, L, true, false, false><<<grid, block, 0, s>>>(a);
+  } else {
+    k_backward_vscan<P, W, L, false, true, false><<<grid, block, 0, s>>>(a);
+  }
+}
+int launch_backward_vscan(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                          const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
+                          hipStream_t s) {
+  if (!vector_problem_ok(p) || (!lam && !dJdu) || g.N < kScanL || g.N % kScanL != 0 || batch < 1 || !g.RECS) return -1;
+  const BwdArgsScan a{g.N, batch, g.RECS, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, lam0, pend0};
+  if (p.functor == Functor::User) {
+    const int kid = lamT ? (lam && dJdu ? UK_VSCAN_LAM_DJDU_LT : (lam ? UK_VSCAN_LAM_LT : UK_VSCAN_DJDU_LT))
+                         : (lam && dJdu ? UK_VSCAN_LAM_DJDU : (lam ? UK_VSCAN_LAM : UK_VSCAN_DJDU));
+    void* args[] = {(void*)&a};
+    return jit_launch(p.user, kid, dim3((batch + 63) / 64), dim3(vscan_waves(p.nS) * 64), args, s);
+  }
+  switch (p.nS) {
+    case 1: run_backward_vscan<LogisticK<1>>(a, s); break;
+    case 2: run_backward_vscan<LogisticK<2>>(a, s); break;
+    case 3: run_backward_vscan<LogisticK<3>>(a, s); break;
+    default: run_backward_vscan<LogisticK<4>>(a, s); break;
+  }
+  return hip_rc6(hipGetLastError());
 }
 
 int scan_chunk_steps() { return kScanL; }

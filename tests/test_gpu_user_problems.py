@@ -219,3 +219,90 @@ def test_lq_problem_bl5_style(ocs, oracle):
     for b in range(3):
         Jo, do, _ = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b])
         assert abs(Jn[b] - Jo) < RTOL * max(1, abs(Jo)) and relerr(dJdv[:, b], do) < RTOL
+
+
+@pytest.mark.parametrize("N,batch", [(120, 128), (64, 64), (203, 192), (8, 64), (1000, 256)])
+def test_vector_mappings_for_coupled_problems(ocs, oracle, N, batch):
+    """OCProblem/OCProblem.m:8-21 allows any coupled F: the predator-prey plugin (full-vector methods through hipRTC) on the
+    vector-lane state pass (csrc/ocs_pipelinev_kernel.hpp: whole tiles of 64 trajectories, whole blocks of 8 steps, the
+    rest of the steps on the lane kernel) and the scan adjoint with dense 2 x 2 step maps (csrc/ocs_vscan_kernel.hpp)
+    against the NumPy twin of RK4Integrator.m and against the lane kernels; explicit lamT, lam only, dJdu only."""
+    pu, pn = ocs.UserProblem(PREDPREY_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS), PredPreyNP()
+    tspan = oracle.linspace(0, 6 if N > 8 else 0.5, N + 1)
+    rng = np.random.default_rng(N)
+    uu = rng.uniform(0.0, 1.0, (1, 2 * N + 1, batch))
+    x0 = rng.uniform(1.0, 2.5, (2, batch))
+    out = {}
+    for mapping in ("auto", "lane"):
+        g = ocs.RK4Integrator(tspan).set_mapping(mapping)
+        x, J = g.compute_states(pu, x0, uu)
+        lam, dJdu = g.compute_adjoints(pu, uu)
+        out[mapping] = (x, J, lam, dJdu)
+    for a_, b_ in zip(out["auto"], out["lane"]):
+        assert relerr(a_, b_) < RTOL
+    assert np.array_equal(out["auto"][0][:2], out["lane"][0][:2])     # the state rows: the same operations in the same order
+    x, J, lam, dJdu = out["auto"]
+    assert np.array_equal(J, x[2, -1, :])                              # J == x(end, end)   RK4Integrator.m:55
+    gn = tw.RK4IntegratorNP(tspan)
+    for b in sorted({0, 1, 63, batch // 2, batch - 1}):
+        xn, Jn = gn.compute_states(pn, x0[:, b], uu[:, :, b])
+        lamn, dn = gn.compute_adjoints(pn, uu[:, :, b])
+        assert relerr(x[:, :, b], xn) < RTOL and abs(J[b] - Jn) < RTOL * max(1, abs(Jn))
+        assert relerr(lam[:, :, b], lamn) < RTOL and relerr(dJdu[:, :, b], dn) < RTOL
+    # explicit lamT (RK4Integrator.m:63-66), and the outputs on their own
+    g = ocs.RK4Integrator(tspan)
+    lamT = rng.normal(size=(3, batch))
+    g.compute_states(pu, x0, uu)
+    lamL, dL = g.compute_adjoints(pu, uu, lamT)
+    gl = ocs.RK4Integrator(tspan).set_mapping("lane")
+    gl.compute_states(pu, x0, uu)
+    lamR, dR = gl.compute_adjoints(pu, uu, lamT)
+    assert relerr(lamL, lamR) < RTOL and relerr(dL, dR) < RTOL
+    import torch
+    dev = torch.device("cuda:0")
+    ud, x0d = torch.tensor(np.ascontiguousarray(uu.transpose(1, 0, 2)), device=dev), torch.tensor(x0, device=dev)
+    g.compute_states_dev(pu, x0d, ud)
+    lam_only, _ = g.compute_adjoints_dev(pu, ud, None, torch.empty((N + 1, 3, batch), dtype=torch.float64, device=dev), None)
+    _, d_only = g.compute_adjoints_dev(pu, ud, None, None, torch.empty_like(ud))
+    torch.cuda.synchronize()
+    assert np.array_equal(lam_only.cpu().numpy().transpose(1, 0, 2), lam)
+    assert np.array_equal(d_only.cpu().numpy().transpose(1, 0, 2), dJdu)
+
+
+def test_vector_mappings_two_controls_and_three_states(ocs, oracle):
+    """nC = 2 and nS = 3 (neither has a row-split mapping): the LQ plugin source with three states and two controls on the
+    vector-lane state pass and the dense-map scan, against the oracle's LQ problem; and the registry's three-state logistic
+    problem (LogisticK<3>) against the oracle."""
+    nS, nC, N, batch = 3, 2, 96, 128
+    A, Bu, q, rdiag = lq_matrices(nS, nC)
+    r = 0.05
+    par = np.concatenate([[r], A.ravel(order="F"), Bu.ravel(order="F"), q, rdiag])
+    bounds = [[-1.0, 1.0]] * nC
+    pu = ocs.UserProblem(lq_source(nS, nC), nS, nC, par, bounds)
+    po = oracle.LQProblem(A, Bu, q, rdiag, r, bounds)
+    tspan = oracle.linspace(0, 2, N + 1)
+    rng = np.random.default_rng(8)
+    uu = rng.uniform(-1, 1, (nC, 2 * N + 1, batch))
+    x0 = rng.normal(size=(nS, batch))
+    g = ocs.RK4Integrator(tspan)
+    x, J = g.compute_states(pu, x0, uu)
+    lam, dJdu = g.compute_adjoints(pu, uu)
+    ref = oracle.batch_states_adjoints(po, tspan, x0, uu)
+    assert relerr(x, ref["x"]) < RTOL and relerr(J, ref["J"]) < RTOL
+    assert relerr(lam, ref["lam"]) < RTOL and relerr(dJdu, ref["dJdu"]) < RTOL
+    gl = ocs.RK4Integrator(tspan).set_mapping("lane")
+    xl, Jl = gl.compute_states(pu, x0, uu)
+    assert relerr(x, xl) < 1e-13 and relerr(J, Jl) < 1e-13
+    # registry, three states
+    m = [3.0, 2.5, 2.0]
+    pb, pob = ocs.LogisticProblem(m, 1.5, 0.05, BOUNDS), oracle.LogisticProblem(m, 1.5, 0.05, BOUNDS)
+    N2 = 200
+    ts2 = oracle.linspace(0, 10, N2 + 1)
+    u2 = rng.uniform(0.05, 0.45, (1, 2 * N2 + 1, 64))
+    x02 = rng.uniform(0.9, 2.0, (3, 64))
+    g2 = ocs.RK4Integrator(ts2)
+    x2, J2 = g2.compute_states(pb, x02, u2)
+    lam2, d2 = g2.compute_adjoints(pb, u2)
+    ref2 = oracle.batch_states_adjoints(pob, ts2, x02, u2)
+    assert relerr(x2, ref2["x"]) < RTOL and relerr(J2, ref2["J"]) < RTOL
+    assert relerr(lam2, ref2["lam"]) < RTOL and relerr(d2, ref2["dJdu"]) < RTOL
