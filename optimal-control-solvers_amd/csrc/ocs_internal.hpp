@@ -74,6 +74,13 @@ bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch);
 int costate_prec();
 int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
                        const int* frozen, double* dump, double* lam, int ld, hipStream_t s, const int* gate = nullptr);
+// the same pass as a scan over time (ocs_costate_scan_kernel.hpp); _met: with the convergence test of the folded sweep
+bool costate_scan_ok(const ProblemDesc& p, const GridDesc& g, int batch);
+int launch_costate_scan(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                        const int* frozen, double* lam, hipStream_t s, const int* gate);
+int launch_costate_scan_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                            const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
+                            double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate);
 int launch_costate_pl(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                       const int* frozen, double* dump, double* lam, int ld, hipStream_t s);
 // pend0: optional [B], the k1 half of column 2N of dJdu when the steps above N were integrated by another kernel

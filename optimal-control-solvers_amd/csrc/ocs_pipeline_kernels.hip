@@ -1321,6 +1321,7 @@ bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch);
 int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
                        const int* frozen, double* dump, double* lam, int ld, hipStream_t s, const int* gate) {
   if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || (frozen && !dump) || !PR) return -1;
+  if (ld == 0 && costate_scan_ok(p, g, batch)) return launch_costate_scan(p, g, batch, x, ldx, PR, frozen, lam, s, gate);
   const CostateXArgs a{CostateArgsPL{g.N, batch, ld, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, frozen, dump, lam}, PR, gate};
   if (p.nS == 1)
     run_costate_plx<LogisticK<1>>(a, s);
@@ -1338,6 +1339,8 @@ int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const
                        const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
                        double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate) {
   if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || !PR || !g.TU || !status || !maxChange || !nactive) return -1;
+  if (costate_scan_ok(p, g, batch))
+    return launch_costate_scan_met(p, g, batch, x, ldx, PR, lb, ub, relTol, absTol, sweep, status, maxChange, nactive, lam, s, gate);
   const CostateXArgs a{CostateArgsPL{g.N, batch, 0, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, status, nullptr, lam},
                        PR, gate, g.TU, lb, ub, relTol, absTol, sweep, status, maxChange, nactive};
   const dim3 grid(batch / (64 / p.nS)), block(576);

@@ -2,6 +2,7 @@
 // record table, and the dispatch to the hipRTC instances of user problems given as row functions.
 #include "ocs_scan_kernel.hpp"
 #include "ocs_vscan_kernel.hpp"
+#include "ocs_costate_scan_kernel.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_jit.hpp"
 #include "ocs_problems.hpp"
@@ -111,6 +112,51 @@ int launch_backward_vscan(const ProblemDesc& p, const GridDesc& g, int batch, co
     default: run_backward_vscan<LogisticK<4>>(a, s); break;
   }
   return hip_rc6(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------
+// costate pass of the sweep as a scan (ocs_costate_scan_kernel.hpp)
+bool costate_scan_ok(const ProblemDesc& p, const GridDesc& g, int batch) {
+  static const bool off = getenv("OCS_COSTATE_SERIAL") != nullptr;   // the serial wave-specialised kernels, for A/B timing
+  static const bool on = getenv("OCS_COSTATE_SCAN") != nullptr;       // ... and the scan at every batch
+  // Selected while the chip has idle CUs (<= 128 workgroups): there the serial kernel's 1000-step chain sets the time
+  // (measured, TestOCProblem, N = 1000, ms per solve of 12 sweeps, scan / serial: batch 2048 2.00 / 2.07, 4096 2.00 / 2.07,
+  // 16 384 2.24 / 2.20 -- at BL-3's batch either pass moves its 24 B per instance-step at ~4.9 TB/s).
+  return !off && scan_supported(p.functor, p.nS, p.nC) && g.RECS && g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 &&
+         (on || batch / (64 / p.nS) <= 128);
+}
+template <class P, bool MET>
+static void run_costate_scan(const CostateScanArgs& a, hipStream_t s) {
+  k_costate_scan<P, kScanW, kScanL, MET><<<dim3(a.batch / (64 / P::NS)), dim3(kScanW * 64), 0, s>>>(a);
+}
+template <bool MET>
+static int launch_costate_scan_t(const ProblemDesc& p, const CostateScanArgs& a, hipStream_t s) {
+  if (p.nS == 1)
+    run_costate_scan<LogisticK<1>, MET>(a, s);
+  else if (p.nS == 2)
+    run_costate_scan<LogisticK<2>, MET>(a, s);
+  else
+    run_costate_scan<LogisticK<4>, MET>(a, s);
+  return hip_rc6(hipGetLastError());
+}
+int launch_costate_scan(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                        const int* frozen, double* lam, hipStream_t s, const int* gate) {
+  if (!costate_scan_ok(p, g, batch) || !PR) return -1;
+  CostateScanArgs a{};
+  a.N = g.N; a.batch = batch; a.RECS = g.RECS; a.PR = PR; a.ps = p.ps; a.pb = p.pb; a.pmask = p.pmask;
+  a.x = x; a.ldx = ldx; a.frozen = frozen; a.lam = lam; a.gate = gate;
+  return launch_costate_scan_t<false>(p, a, s);
+}
+int launch_costate_scan_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                            const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
+                            double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate) {
+  if (!costate_scan_ok(p, g, batch) || !PR || !g.TU || !status || !maxChange || !nactive) return -1;
+  CostateScanArgs a{};
+  a.N = g.N; a.batch = batch; a.RECS = g.RECS; a.PR = PR; a.ps = p.ps; a.pb = p.pb; a.pmask = p.pmask;
+  a.x = x; a.ldx = ldx; a.frozen = status; a.lam = lam; a.gate = gate;
+  a.TU = g.TU; a.lb = lb; a.ub = ub; a.relTol = relTol; a.absTol = absTol; a.sweep = sweep; a.status = status;
+  a.maxChange = maxChange; a.nactive = nactive;
+  return launch_costate_scan_t<true>(p, a, s);
 }
 
 int scan_chunk_steps() { return kScanL; }
