@@ -158,7 +158,7 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=5, shard=True):
         if n_local == 16384 and NSTEPS == 1000:
             fb_traffic = tr["hbm_bytes_per_batch_sweep"]
             fb_traffic_source = (f"profiles/{tr['tag']}_fb_sweep_traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, "
-                                 "k_forward_cc + k_costate_plx per live launch; replayed from that file, not collected by this run)")
+                                 "k_forward_cc + the costate kernel per live launch; replayed from that file, not collected by this run)")
     except Exception:
         fb_traffic = None
     return {"value": iters / dt, "unit": "fb_sweep iters/s (instance-sweeps)", "batch": batch, "n_steps": NSTEPS,
@@ -255,11 +255,11 @@ def bl4_metric(ocs, dev, batch=65536, reps=5, shard=True):
 
 
 def _replayed_traffic(name, nloc):
-    """HBM bytes per launch pair from a committed rocprofv3 PMC summary under profiles/ (replayed, not collected by this
-    run), if it was taken at this local batch."""
+    """HBM bytes per evaluation (both kernels) from the committed rocprofv3 PMC summary under profiles/ (scripts/profile_r03.sh
+    + summarize_r03.py; replayed, not collected by this run), if one was taken at this local batch."""
     try:
-        tr = json.load(open(os.path.join(ROOT, "profiles", name)))
-        if tr.get("batch") == nloc:
+        tr = json.load(open(os.path.join(ROOT, "profiles", name)))["entries"].get(str(nloc))
+        if tr:
             return tr["hbm_bytes_per_evaluation"], f"{tr['source']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; replayed)"
     except Exception:
         pass
@@ -430,13 +430,21 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2, shard=True):
     fl_fwd = 4 * 2 * nS * nS + 3 * 2 * nS * nC
     fl_bwd = 7 * 2 * nS * nS + 2 * 2 * nS * nC + 2 * 2 * nS * nC
     tfl_b = steps_local * fl_bwd / tb / 1e12
+    tr5 = (None, None)
+    try:   # HBM bytes of the adjoint kernels of a pass pair, replayed from the committed PMC summary
+        t5 = json.load(open(os.path.join(ROOT, "profiles", "bl5_traffic_latest.json")))
+        if t5.get("batch") == nloc and N == 4000:
+            kb = sum(v["hbm_bytes_per_launch"] for k, v in t5["kernels"].items() if "backward" in k)
+            tr5 = (kb, f"{t5['source']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, k_lq2_backward of both legs; replayed)")
+    except Exception:
+        pass
     return {"value": batch * 2 * N / dt, "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
             "batch": batch, "batch_per_gpu": nloc, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3,
             "ms_adjoint": tb * 1e3, "ms_pass_pair_max_over_ranks": dt * 1e3,
             "roofline": {"bound": "mfma", "kernel": "k_lq2_backward (adjoint + dJdu, both legs; two waves per 16 "
                                                     "trajectories), this rank",
                          "achieved": tfl_b, "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": tfl_b / FP64_MFMA_PEAK_TFLOPS, "traffic": None, "traffic_source": None,
+                         "frac": tfl_b / FP64_MFMA_PEAK_TFLOPS, "traffic": tr5[0], "traffic_source": tr5[1],
                          "algorithmic_flops_per_trajectory_step": fl_bwd},
             "pass_pair_TFLOPs": steps_local * (fl_fwd + fl_bwd) / (tf + tb) / 1e12,
             "finite": bool(torch.isfinite(lam[0]).all().item()) and bool(torch.isfinite(J).all().item())}
