@@ -32,6 +32,9 @@ for batch in [int(b) for b in os.environ.get('BATCHES', '64,8192,65536').split('
         res[mode] = (J.cpu().numpy(), dv.cpu().numpy())
         print(f"batch {batch} nB {nB} mode {mode}: {ms*1e3:.1f} us per evaluation, {batch*N/(ms*1e-3):.3e} steps/s, "
               f"16 B/step: {16*batch*N/(ms*1e-3)/1e12:.2f} TB/s", flush=True)
+    if os.environ.get('DUMP'):
+        for k, (Jv, dv_) in res.items():
+            np.savez(f"{os.environ['DUMP']}_{batch}_{k}.npz", J=Jv, dJdv=dv_)
     ks = list(res)
     for k in ks[1:]:
         a, b = res[ks[0]], res[k]

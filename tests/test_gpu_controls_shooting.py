@@ -363,11 +363,15 @@ def test_dense_basis_kernels_large_batch(ocs, oracle):
 
 
 @pytest.mark.parametrize("nS,nB,N,batch", [(1, 16, 1000, 70), (1, 5, 7, 3), (2, 20, 50, 130), (4, 32, 64, 64),
-                                           (3, 1, 9, 65)])
+                                           (3, 1, 9, 65), (2, 12, 48, 130), (1, 9, 16, 200), (2, 16, 8, 1),
+                                           (1, 3, 24, 64)])
 def test_fused_control_objective_gradient(ocs, oracle, nS, nB, N, batch):
     """single_shooting.m:137-150 with ChebyshevControl.m:35-43 applied inside the RK4 kernels (u and dJdu never in
     memory) against the oracle's unfused composition and against this library's own unfused path; free initial
-    states (:144-149) and a per-trajectory parameter included."""
+    states (:144-149) and a per-trajectory parameter included.  Shapes with N % 8 == 0, nB <= 16, nS <= 2 run the
+    two-role kernels (integrator wave + basis wave, k_forward_fc2 / k_backward_fc2: one, two, three and 125 blocks,
+    odd and even block counts, partial last wave), the others the one-wave lane kernels; (1, 3, 24, 64) is forced
+    onto the lane kernels below ("lane"), its shape would otherwise take the wave-specialised path."""
     m = [3.0, 2.5, 2.0, 1.5][:nS]
     T = 10.0 if N >= 50 else 1.0
     tspan = oracle.linspace(0, T, N + 1)
@@ -383,10 +387,10 @@ def test_fused_control_objective_gradient(ocs, oracle, nS, nB, N, batch):
     pg = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
     pg.set_batch_params([0], cs[None, :])   # LogisticK parameter block [c r m_1..m_nS]: c per trajectory
     out = {}
-    for mode in ("on", "off"):
+    for mode in ("lane", "off"):
         cg.set_fusion(mode)
         out[mode] = ocs.nlp_objective(g, pg, cg, x0.copy(), V, FreeInitStates=free)
-    Jf, df, x0f = out["on"]
+    Jf, df, x0f = out["lane"]
     Ju, du, x0u = out["off"]
     assert relerr(Jf, Ju) < 1e-13 and relerr(df, du) < RTOL and np.array_equal(x0f, x0u)
     for b in sorted({0, batch // 2, batch - 1}):
@@ -468,10 +472,10 @@ def test_fused_banded_control_objective_gradient(ocs, oracle, kind, nS, nB, N, b
     pg = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
     pg.set_batch_params([0], cs[None, :])
     out = {}
-    for mode in ("on", "off"):
+    for mode in ("lane", "off"):
         cg.set_fusion(mode)
         out[mode] = ocs.nlp_objective(g, pg, cg, x0.copy(), V, FreeInitStates=free)
-    Jf, df, x0f = out["on"]
+    Jf, df, x0f = out["lane"]
     Ju, du, x0u = out["off"]
     assert relerr(Jf, Ju) < 1e-13 and relerr(df, du) < RTOL and np.array_equal(x0f, x0u)
     for b in sorted({0, batch // 2, batch - 1}):
