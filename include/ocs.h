@@ -82,7 +82,11 @@ int ocs_problem_create(ocs_problem *out, int problem_id, int nS, int nC, const d
  * ocs_ControlChar; bit 1 (value 2) -- the problem is ROW-SEPARABLE and the source defines row functions (ocs_row_F,
  * ocs_row_q, ocs_row_dFdy, ocs_row_dFdu: row r of F reads y_r, u and t only, the integrand is a sum of per-row shares;
  * nC = 1, nS in {1, 2, 4}, at most 16 parameters) from which the three methods are derived: such a problem also runs on
- * the wave-specialised state pass and the scan adjoint pass, the mappings of the registry problems.
+ * the wave-specialised state pass and the scan adjoint pass, the mappings of the registry problems;
+ * bit 2 (value 4, with bits 0 and 1) -- the problem declares that ocs_ControlChar does not read x and ocs_row_dFdy does
+ * not read u (the control of the minimum principle is a function of the costate alone, functions/fb_sweep.m:94-97 with
+ * the Gen-1 ControlChar of make_from_symbolic.m:33-38 for a Hamiltonian separable in (x, u)): fb_sweep then runs its
+ * two-kernel sweep for the problem (ocs_fb_sweep_path == 4); ocs_ControlChar receives x = zeros, ocs_row_dFdy u = 0 there.
  * A compile error returns OCS_ERR_INVALID with the compiler log in ocs_last_error().  ocs_problem_check_source only
  * compiles (no GPU needed). */
 int ocs_problem_create_from_source(ocs_problem *out, const char *source, int nS, int nC, const double *params,
@@ -295,6 +299,14 @@ int ocs_fb_sweep(ocs_integrator g, ocs_problem p, int batch, const double *x0, c
 int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double *x0, const ocs_fbs_options *opt,
                      const double *u0grid, const double *u0err, double *xaug, double *lam, double *uInterp,
                      double *J, int *sweeps, double *maxChange, void *stream);
+/* Diagnostic: the sweep loop the last ocs_fb_sweep(_dev) on this integrator ran --
+ * 0 none yet; 1 the reference's sequence kernel by kernel (state pass, pchip midpoints, costate pass, ControlChar on the
+ * error points / the grid, convergence bookkeeping, one host round trip per sweep); 2 the same with the control update
+ * fused into one kernel and sweeps enqueued one ahead; 3 windows of the batch on their own streams; 4 the two-kernel
+ * sweep (state pass with the control update folded in + costate pass with the convergence test, csrc/ocs_fold_kernel.hpp):
+ * registry problems of the logistic family and hipRTC problems created with flag bit 2 (row functions, ocs_ControlChar of
+ * the costate alone). */
+int ocs_fb_sweep_path(ocs_integrator g);
 
 /* ---- the batch axis over the GPUs of one node (the reference has no batch axis and no parallelism:
  * every entry point integrates one trajectory, tests/solve_test_problem.m:37) ----

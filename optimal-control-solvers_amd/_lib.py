@@ -44,6 +44,7 @@ _SIG = {
     "ocs_set_device": (C.c_int, [C.c_int]),
     "ocs_synchronize": (C.c_int, []),
     "ocs_problem_create": (C.c_int, [C.POINTER(vp), C.c_int, C.c_int, C.c_int, dp, C.c_int, dp]),
+    "ocs_fb_sweep_path": (C.c_int, [vp]),
     "ocs_problem_create_from_source": (C.c_int, [C.POINTER(vp), C.c_char_p, C.c_int, C.c_int, dp, C.c_int, dp, C.c_int]),
     "ocs_problem_check_source": (C.c_int, [C.c_char_p, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ocs_problem_destroy": (C.c_int, [vp]),

@@ -1,7 +1,8 @@
 // ocs_costate_scan_kernel.hpp -- the costate pass of the forward-backward sweep (functions/compute_x_lam.m:11-14,
 // lam' = adjointRHS(t, x(t), lam, u(t)), lam(TF) = 0, integrated backwards; here RK4 on the node grid with x(t) the
-// pchip interpolant of the node values) as a scan over time, for the row-separable registry problems
-// whose adjoint right-hand side does not read u.
+// pchip interpolant of the node values) as a scan over time, for row-separable problems whose adjoint
+// right-hand side does not read u: the registry's logistic family and hipRTC problems given as row functions that declare
+// it (OCS_USER_CC_NOX, ocs_user_functor.hpp).
 //
 // adjointRHS = -dFdx_times_vec(t, [x; 0], u, [lam; 1])(1:nS) (the A9 adapter) is affine in lam, so an RK4
 // step from t_{i+1} down to t_i is an affine map per row, lam_i = alpha_i lam_{i+1} + beta_i, whose coefficients depend on
@@ -169,13 +170,13 @@ __global__ __launch_bounds__(W * 64) void k_costate_scan(const CostateScanArgs a
     for (int q = 0; q < L; ++q) {
       const double* rc = recs + q * kScanRec;
       const double h = rc[0], hh = rc[1], h6 = rc[2];
-      const double eA = 2.0 * rc[8], eM = 2.0 * rc[9], eB = 2.0 * rc[10];   // 2 e^{-r t} at the left node, the middle, the right node
+      const double eA = rc[8], eM = rc[9], eB = rc[10];   // time coefficient at the left node, the middle, the right node
       const double xA = d.w[q + 1], xB = d.w[q + 2];
       const double xM = __builtin_fma(prs[q * kPRec + 11], dsl[q] - dsl[q + 1], 0.5 * (xA + xB));
       double aA, bA, aM, bM, aB, bB;
-      P::row_dfdx_pre(xA, eA, rp, aA, bA);
-      P::row_dfdx_pre(xM, eM, rp, aM, bM);
-      P::row_dfdx_pre(xB, eB, rp, aB, bB);
+      P::costate_row_pre(xA, eA, rp, aA, bA);
+      P::costate_row_pre(xM, eM, rp, aM, bM);
+      P::costate_row_pre(xB, eB, rp, aB, bB);
       // the RK4 step of k_costate_plx on the pair (coefficient of lam_{i+1}, constant):
       //   k1 = -(aB l + bB);  L = l - hh k1;  k2 = -(aM L + bM);  L = l - hh k2;  k3 = -(aM L + bM);  L = l - h k3;
       //   k4 = -(aA L + bA);  l <- l - h6 (k1 + 2 k2 + 2 k3 + k4)
@@ -225,10 +226,18 @@ __global__ __launch_bounds__(W * 64) void k_costate_scan(const CostateScanArgs a
       if (MET) {
         // ControlChar reads the costate of all rows: the sum over the rows of an instance, in every lane of the instance
         double ln[G], lo_[G];
-        ln[0] = group_sum_sc<G>(lam);
-        lo_[0] = group_sum_sc<G>(d.lo_[q]);
+        if constexpr (P::HAS_SHIFT) {   // registry rows: ControlChar reads the sum of the costate rows only
+          ln[0] = group_sum_sc<G>(lam);
+          lo_[0] = group_sum_sc<G>(d.lo_[q]);
 #pragma unroll
-        for (int k = 1; k < G; ++k) ln[k] = lo_[k] = 0.0;
+          for (int k = 1; k < G; ++k) ln[k] = lo_[k] = 0.0;
+        } else {                        // any ControlChar: every lane of an instance gets the costate of all its rows
+#pragma unroll
+          for (int k = 0; k < G; ++k) {
+            ln[k] = __shfl(lam, k * TPW + tl);
+            lo_[k] = __shfl(d.lo_[q], k * TPW + tl);
+          }
+        }
         const double tu = d.tu[q];
         const double un = P::control_char_pre(tu, ln, ccp, lbv, ubv), uo = P::control_char_pre(tu, lo_, ccp, lbv, ubv);
         if (live) take(un, u0lb ? lbv : uo);   // (wave-uniform)

@@ -17,6 +17,7 @@ struct ocs_fbs_state {
   // query-point tables (error points / interp points), rebuilt when the options change
   int nerr = 0, nint = 0;
   bool err_on_nodes = false;  // the error points are the grid nodes (the default on a linspace tspan)
+  int last_path = 0;          // ocs_fb_sweep_path
   DevBuf KE, SE, TE, TUE, KI, SI, TI, TUI;
   unsigned long long tu_version = 0;
   const ocs_problem_s* tu_prob = nullptr;
@@ -420,8 +421,12 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const FbsTables tb = tabs(g);
   // every sweep with the control update folded into the state pass (see below): the grid samples of u are never formed
   // (not with a damped update: that needs the samples of the control it damps)
-  const bool fold = fusedup && om == 1.0 && opt->nWINDOWS <= 1 && opt->fused_update_off == 0 && costate_forms_midpoints(pd, N, batch) &&
-                    forward_gate_supported(pd, gd, batch) && fold_supported(pd, gd, batch);
+  // (registry problems: where the wave-specialised costate kernels and the gated state pass apply; hipRTC problems: row
+  //  functions whose ocs_ControlChar reads the costate alone, fold_supported)
+  const bool userfold = p->user != nullptr && fold_supported(pd, gd, batch);
+  const bool fold = fusedup && om == 1.0 && opt->nWINDOWS <= 1 && opt->fused_update_off == 0 &&
+                    (userfold || (costate_forms_midpoints(pd, N, batch) && forward_gate_supported(pd, gd, batch) &&
+                                  fold_supported(pd, gd, batch)));
   if (u0grid) {  // u = u0  :76
     HIP_TRY(hipMemcpyAsync(f->ugrid.p, u0grid, sizeof(double) * ugridN, hipMemcpyDeviceToDevice, s));
     HIP_TRY(hipMemcpyAsync(f->uerr.p, u0err, sizeof(double) * uerrN, hipMemcpyDeviceToDevice, s));
@@ -432,6 +437,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   }
   const int* usel = (const int*)f->usel.p;  // selects the old / new buffer of the ERROR-POINT samples only
   int nactive = batch;
+  f->last_path = 1;
   // ---- fused update, several windows of the batch on their own streams -----------------------------------------
   // The two marching kernels of a sweep (forward, costate) are latency-bound and leave most of the GPU idle; the
   // streaming kernels (pchip, control update) are HBM-bound.  Independent windows of the batch, each running its own
@@ -446,6 +452,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     while (nwin > 1 && (batch + nwin - 1) / nwin < 64) --nwin;
   }
   if (fusedup && nwin > 1) {
+    f->last_path = 3;
     const int W = (((batch + nwin - 1) / nwin + 63) / 64) * 64;  // whole tiles of the pipeline kernels
     nwin = (batch + W - 1) / W;
     const int nsw = opt->nSWEEPS;
@@ -525,9 +532,10 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // start with a look at sweep k's device counter: if no instance was left, they return at once (a sweep over
   // converged instances would change nothing anyway -- they are frozen -- but would cost its full time).
   bool spec_done = false;
-  if (fusedup && nwin == 1 && fuo == 0 && costate_forms_midpoints(pd, N, batch) &&
-      forward_gate_supported(pd, gd, batch)) {
+  if (fusedup && nwin == 1 && fuo == 0 &&
+      (fold || (costate_forms_midpoints(pd, N, batch) && forward_gate_supported(pd, gd, batch)))) {
     const int nsw = opt->nSWEEPS;
+    f->last_path = fold ? 4 : 2;
     if (f->h_nact_cap < nsw) {
       if (f->h_nact) (void)hipHostFree(f->h_nact);
       f->h_nact = nullptr;
@@ -634,6 +642,8 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
                                 uInterp, nullptr, 0, nullptr, nullptr, 0.0, 0.0, s));
   return nactive > 0 ? OCS_NUM_NOT_CONVERGED : OCS_OK;
 }
+
+int ocs_fb_sweep_path(ocs_integrator g) { return (g && g->fbs) ? g->fbs->last_path : 0; }
 
 // host: x0 nS x batch; u0grid nC x (2N+1) x batch, u0err nC x nERR x batch (or both NULL);
 // x nS x (N+1) x batch, lam nS x (N+1) x batch, uInterp nC x nINTERP x batch, J batch, sweeps batch,

@@ -2,7 +2,8 @@
 // the default start u0 = lower bound in the place of ControlChar of a costate that does not exist yet).
 //
 // fb_sweep.m:79-87 alternates  [x, lam] = compute_x_lam(u)  and  u = ControlChar(t, x(t), lam(t))  on the grid.  For the
-// problems of the wave-specialised kernels ControlChar does not read x, so the control a state pass integrates is a
+// problems of the wave-specialised kernels (the registry's logistic family; hipRTC problems given as row functions that
+// declare it, OCS_USER_CC_NOX in ocs_user_functor.hpp) ControlChar does not read x, so the control a state pass integrates is a
 // function of the PREVIOUS sweep's costate alone: u_k(t) = ControlChar(t, lam_{k-1}(t)), with lam at the half steps by
 // pchip (compute_x_lam.m:11-14 / vectorInterpolant).  Writing those 2N+1 samples per instance to memory and reading
 // them back was the largest kernel of a sweep (k_control_grid: 24 B per instance and step written, 8 + 8 read);
@@ -84,7 +85,7 @@ struct FwdArgsCC {
 template <class P, bool UNI>
 __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const FwdArgsCC a) {
   constexpr int G = P::NS, NAUG = P::NAUG;
-  static_assert(P::NC == 1 && P::NTC == 1 && P::NTU == 1 && P::HAS_SHIFT, "fold: one control, shifted row form");
+  static_assert(P::NC == 1 && P::NTC == 1 && P::NTU == 1 && P::ROW_SEPARABLE && !P::CC_READS_X, "fold: one control, uncoupled rows, ControlChar of the costate alone");
   using C_ = FoldCfg<G>;
   constexpr int D = C_::D, TPW = C_::TPW, Q = C_::Q, NSLOT = C_::NSLOT, RS = C_::RS, SCO = C_::SCO;
   constexpr int NCW = C_::NCW, SPW = C_::SPW;
@@ -285,22 +286,45 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
           return v;
         };
         In nxt = fetch(0);
+        if constexpr (P::HAS_SHIFT) {
 #pragma unroll
-        for (int s = 0; s < D; ++s) {
-          const In c = nxt;
-          if (s + 1 < D) nxt = fetch(s + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          const double cM = c.c.x, cB = c.c.y;
-          zw[s * 64] = z;
-          const double F1 = P::row_f_shifted(z, cprev);
-          double Z = __builtin_fma(c.hh, F1, z);
-          const double F2 = P::row_f_shifted(Z, cM);
-          Z = __builtin_fma(c.hh, F2, z);
-          const double F3 = P::row_f_shifted(Z, cM);
-          Z = __builtin_fma(c.h, F3, z);
-          const double F4 = P::row_f_shifted(Z, cB);
-          z = __builtin_fma(c.h6, F4, __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)), z));
-          cprev = cB;
+          for (int s = 0; s < D; ++s) {
+            const In c = nxt;
+            if (s + 1 < D) nxt = fetch(s + 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const double cM = c.c.x, cB = c.c.y;
+            zw[s * 64] = z;
+            const double F1 = P::row_f_shifted(z, cprev);
+            double Z = __builtin_fma(c.hh, F1, z);
+            const double F2 = P::row_f_shifted(Z, cM);
+            Z = __builtin_fma(c.hh, F2, z);
+            const double F3 = P::row_f_shifted(Z, cM);
+            Z = __builtin_fma(c.h, F3, z);
+            const double F4 = P::row_f_shifted(Z, cB);
+            z = __builtin_fma(c.h6, F4, __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)), z));
+            cprev = cB;
+          }
+        } else {
+          // row functions (user problems): no shifted form -- wave P hands the samples on as they are (row_vertex is the
+          // identity there), the row function gets the stage's time coefficient from the step record
+#pragma unroll
+          for (int s = 0; s < D; ++s) {
+            const In c = nxt;
+            if (s + 1 < D) nxt = fetch(s + 1);
+            const double tA = rec[RS * s + 4], tM = rec[RS * s + 5], tB = rec[RS * s + 6];
+            __builtin_amdgcn_sched_barrier(0);
+            const double uM = c.c.x, uB = c.c.y;
+            zw[s * 64] = z;
+            const double F1 = P::g_row_f(z, cprev, tA, rp);
+            double Y = __builtin_fma(c.hh, F1, z);
+            const double F2 = P::g_row_f(Y, uM, tM, rp);
+            Y = __builtin_fma(c.hh, F2, z);
+            const double F3 = P::g_row_f(Y, uM, tM, rp);
+            Y = __builtin_fma(c.h, F3, z);
+            const double F4 = P::g_row_f(Y, uB, tB, rp);
+            z = __builtin_fma(c.h6, F4, __builtin_fma(c.h6, __builtin_fma(2.0, F3, __builtin_fma(2.0, F2, F1)), z));
+            cprev = uB;
+          }
         }
       }
     }
@@ -347,27 +371,52 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
           double zq[G];
 #pragma unroll
           for (int q = 0; q < G; ++q) zq[q] = zr[s * 64 + q * TPW + ctl];
-          const double uA2 = uA * uA, uM2 = uM * uM, uB2 = uB * uB;
-          const double cqM = P::control_q(uM2, rpr[0]);
-          double q1 = P::control_q(uA2, rpr[0]), q2 = cqM, q3 = cqM, q4 = P::control_q(uB2, rpr[0]);
+          double d;
+          if constexpr (P::HAS_SHIFT) {
+            const double uA2 = uA * uA, uM2 = uM * uM, uB2 = uB * uB;
+            const double cqM = P::control_q(uM2, rpr[0]);
+            double q1 = P::control_q(uA2, rpr[0]), q2 = cqM, q3 = cqM, q4 = P::control_q(uB2, rpr[0]);
 #pragma unroll
-          for (int q = 0; q < G; ++q) {
-            const double z = zq[q], mh = mhr[q];
-            const double cA = P::row_vertex(mh, uA), cM = P::row_vertex(mh, uM);
-            const double F1 = P::row_f_shifted(z, cA);
-            const double Z2 = __builtin_fma(hh, F1, z);
-            const double F2 = P::row_f_shifted(Z2, cM);
-            const double Z3 = __builtin_fma(hh, F2, z);
-            const double F3 = P::row_f_shifted(Z3, cM);
-            const double Z4 = __builtin_fma(h, F3, z);
-            const double y1 = z + mh;
-            q1 = P::state_q_acc(y1, q1);
-            q2 = P::state_q_acc(Z2 + mh, q2);
-            q3 = P::state_q_acc(Z3 + mh, q3);
-            q4 = P::state_q_acc(Z4 + mh, q4);
-            bx.st(y1, vx, (unsigned)s0 * col8 + (unsigned)q * B8);
+            for (int q = 0; q < G; ++q) {
+              const double z = zq[q], mh = mhr[q];
+              const double cA = P::row_vertex(mh, uA), cM = P::row_vertex(mh, uM);
+              const double F1 = P::row_f_shifted(z, cA);
+              const double Z2 = __builtin_fma(hh, F1, z);
+              const double F2 = P::row_f_shifted(Z2, cM);
+              const double Z3 = __builtin_fma(hh, F2, z);
+              const double F3 = P::row_f_shifted(Z3, cM);
+              const double Z4 = __builtin_fma(h, F3, z);
+              const double y1 = z + mh;
+              q1 = P::state_q_acc(y1, q1);
+              q2 = P::state_q_acc(Z2 + mh, q2);
+              q3 = P::state_q_acc(Z3 + mh, q3);
+              q4 = P::state_q_acc(Z4 + mh, q4);
+              bx.st(y1, vx, (unsigned)s0 * col8 + (unsigned)q * B8);
+            }
+            d = __builtin_fma(wA, q1, __builtin_fma(wM, q2 + q3, wB * q4));
+          } else {
+            // row functions: the integrand at the four stage states as the reference sums it (RK4Integrator.m:50),
+            // k_forward_p2's generic branch
+            const double h6 = rec[RS * s + 2], tA = rec[RS * s + 4], tM = rec[RS * s + 5], tB = rec[RS * s + 6];
+            (void)wA; (void)wM; (void)wB;
+            double q1 = 0.0, q2 = 0.0, q3 = 0.0, q4 = 0.0;
+#pragma unroll
+            for (int q = 0; q < G; ++q) {
+              const double y = zq[q];
+              const double F1 = P::g_row_f(y, uA, tA, rpr[q]);
+              const double Y2 = __builtin_fma(hh, F1, y);
+              const double F2 = P::g_row_f(Y2, uM, tM, rpr[q]);
+              const double Y3 = __builtin_fma(hh, F2, y);
+              const double F3 = P::g_row_f(Y3, uM, tM, rpr[q]);
+              const double Y4 = __builtin_fma(h, F3, y);
+              q1 += P::g_row_q(y, uA, tA, rpr[q]);
+              q2 += P::g_row_q(Y2, uM, tM, rpr[q]);
+              q3 += P::g_row_q(Y3, uM, tM, rpr[q]);
+              q4 += P::g_row_q(Y4, uB, tB, rpr[q]);
+              bx.st(y, vx, (unsigned)s0 * col8 + (unsigned)q * B8);
+            }
+            d = h6 * (__builtin_fma(2.0, q3, __builtin_fma(2.0, q2, q1)) + q4);
           }
-          const double d = __builtin_fma(wA, q1, __builtin_fma(wM, q2 + q3, wB * q4));
           if (csub < G) dd[j & 1][s][ctl] = d;
         }
       }

@@ -2,6 +2,7 @@
 // (ocs_fold_kernel.hpp); registry problems whose ControlChar does not read x.
 #include "ocs_fold_kernel.hpp"
 #include "ocs_internal.hpp"
+#include "ocs_jit.hpp"
 #include "ocs_problems.hpp"
 #include <cstdio>
 
@@ -10,7 +11,10 @@ namespace ocs {
 static inline int hip_rc7(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 
 bool fold_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
-  if (p.functor != Functor::Logistic || p.nC != 1 || !(p.nS == 1 || p.nS == 2 || p.nS == 4)) return false;
+  if (p.nC != 1 || !(p.nS == 1 || p.nS == 2 || p.nS == 4)) return false;
+  if (p.functor == Functor::User)   // hipRTC instances; the costate pass is the scan kernel (costate_scan_ok)
+    return user_fold(p.user) && g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 && costate_scan_ok(p, g, batch) && g.TU && g.REC;
+  if (p.functor != Functor::Logistic) return false;
   return g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 && costate_forms_midpoints(p, g.N, batch) && g.TU && g.REC;
 }
 
@@ -29,6 +33,11 @@ int launch_forward_cc(const ProblemDesc& p, const GridDesc& g, int batch, const 
                       bool no_cost_row, const int* gate, bool first_sweep, hipStream_t s) {
   if (!fold_supported(p, g, batch) || !PR || !lam || !x || !J) return -1;
   const FwdArgsCC a{g.N, batch, g.REC, PR, g.TU, p.ps, p.pb, p.pmask, lb, ub, x0, lam, x, J, frozen, no_cost_row ? 1 : 0, gate, first_sweep ? 1 : 0};
+  if (p.functor == Functor::User) {
+    const int nwave = p.nS == 1 ? FoldCfg<1>::NWAVE : (p.nS == 2 ? FoldCfg<2>::NWAVE : FoldCfg<4>::NWAVE);
+    void* args[] = {(void*)&a};
+    return jit_launch(p.user, g.uniform ? UK_FWD_CC_UNI : UK_FWD_CC, dim3(batch / (64 / p.nS)), dim3(nwave * 64), args, s);
+  }
   if (p.nS == 1)
     run_forward_cc<LogisticK<1>>(a, g.uniform, s);
   else if (p.nS == 2)

@@ -49,6 +49,9 @@ bool pipeline_problem_ok(const ProblemDesc& p);
 // (ocs_pipelinev_kernel.hpp; whole blocks of 8 steps, whole tiles of 64 trajectories) and the scan adjoint pass with
 // dense step maps (ocs_vscan_kernel.hpp; N a multiple of scan_chunk_steps())
 bool user_vector(const UserModule* m);
+// a user problem given as row functions whose ocs_ControlChar reads the costate alone and whose ocs_row_dFdy does not
+// read u (flag bit 2): the folded sweep of fb_sweep is instantiated for it
+bool user_fold(const UserModule* m);
 bool vector_problem_ok(const ProblemDesc& p);
 int launch_forward_pv(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u, double* x,
                       double* J, hipStream_t s, bool no_cost_row, const int* gate);

@@ -63,7 +63,7 @@ static Rtc* rtc() {
 
 int user_chunk(int nS) { return nS <= 4 ? 4 : 1; }
 
-static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep) {
+static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep, bool fold) {
   const std::string ch = std::to_string(user_chunk(nS));
   std::vector<std::string> n(UK_COUNT);
   n[UK_TCOEF] = "ocs::k_tcoef<ocs::UserP>";
@@ -92,6 +92,11 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep) {
     n[UK_SCAN_LAM_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", true, false, true, 0>";
     n[UK_SCAN_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", false, true, true, 0>";
   }
+  if (fold) {
+    n[UK_FWD_CC_UNI] = "ocs::k_forward_cc<ocs::UserP, true>";
+    n[UK_FWD_CC] = "ocs::k_forward_cc<ocs::UserP, false>";
+    n[UK_COSTATE_SCAN_MET] = "ocs::k_costate_scan<ocs::UserP, " + wl + ", true>";
+  }
   if (!rowsep && vector_shape_ok(nS, nC)) {
     const std::string vw = std::to_string(vscan_waves(nS)) + ", " + std::to_string(kVScanL);
     n[UK_FWD_PV_X] = "ocs::k_forward_pv<ocs::UserP, true>";
@@ -108,7 +113,7 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep) {
 
 // Compiles the user's source.  `load` = false stops after compilation (usable without a GPU).
 int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool load, UserModule** out,
-              std::string& log, bool rowsep) {
+              std::string& log, bool rowsep, bool ccnox) {
   Rtc* r = rtc();
   if (!r) {
     log = "hipRTC (libhiprtc.so) could not be loaded";
@@ -120,6 +125,8 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
          "\n#define OCS_USER_NPAR " + std::to_string(npar) + "\n";
   if (has_cc) src += "#define OCS_USER_HAS_CONTROLCHAR 1\n";
   if (rowsep) src += "#define OCS_USER_ROWSEP 1\n";
+  const bool fold = rowsep && has_cc && ccnox;
+  if (fold) src += "#define OCS_USER_CC_NOX 1\n";
   src += "#include \"ocs_device_common.hpp\"\n";
   src += "constexpr int NS = OCS_USER_NS, NC = OCS_USER_NC, NPAR = OCS_USER_NPAR;\n";
   src += (npar <= 16 && !rowsep) ? "typedef const double* OCS_PARAMS;\n" : "typedef ocs::uniform_ptr OCS_PARAMS;\n";
@@ -127,21 +134,24 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   src += user_src;
   src += "\n#include \"ocs_user_functor.hpp\"\n#include \"ocs_rk4_kernels.hpp\"\n#include \"ocs_fbs_device.hpp\"\n";
   if (rowsep) src += "#include \"ocs_pipeline2_kernel.hpp\"\n#include \"ocs_scan_kernel.hpp\"\n";
+  if (fold) src += "#include \"ocs_fold_kernel.hpp\"\n#include \"ocs_costate_scan_kernel.hpp\"\n";
   const bool vec = !rowsep && vector_shape_ok(nS, nC);
   if (vec) src += "#include \"ocs_pipelinev_kernel.hpp\"\n#include \"ocs_vscan_kernel.hpp\"\n";
 
   const char* hdr_src[] = {src_ocs_device_common_hpp, src_ocs_user_functor_hpp, src_ocs_rk4_kernels_hpp,
                            src_ocs_fbs_device_hpp, src_ocs_pipeline2_kernel_hpp, src_ocs_scan_kernel_hpp,
-                           src_ocs_pipelinev_kernel_hpp, src_ocs_vscan_kernel_hpp};
+                           src_ocs_pipelinev_kernel_hpp, src_ocs_vscan_kernel_hpp, src_ocs_fold_kernel_hpp,
+                           src_ocs_costate_scan_kernel_hpp};
   const char* hdr_name[] = {"ocs_device_common.hpp", "ocs_user_functor.hpp", "ocs_rk4_kernels.hpp",
                             "ocs_fbs_device.hpp", "ocs_pipeline2_kernel.hpp", "ocs_scan_kernel.hpp",
-                            "ocs_pipelinev_kernel.hpp", "ocs_vscan_kernel.hpp"};
+                            "ocs_pipelinev_kernel.hpp", "ocs_vscan_kernel.hpp", "ocs_fold_kernel.hpp",
+                            "ocs_costate_scan_kernel.hpp"};
   hiprtcProgram prog = nullptr;
-  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 8, hdr_src, hdr_name) != 0) {
+  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 10, hdr_src, hdr_name) != 0) {
     log = "hiprtcCreateProgram failed";
     return OCS_ERR_HIP;
   }
-  const std::vector<std::string> names = kernel_names(nS, nC, rowsep);
+  const std::vector<std::string> names = kernel_names(nS, nC, rowsep, fold);
   for (const std::string& n : names)
     if (!n.empty()) r->AddNameExpression(prog, n.c_str());
   // The include directory of the ROCm installation explicitly: hipRTC normally serves <hip/hip_runtime.h> from a built-in
@@ -170,6 +180,7 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   m->has_cc = has_cc;
   m->rowsep = rowsep;
   m->vector = vec;
+  m->fold = fold;
   m->chunk = user_chunk(nS);
   std::vector<std::string> lowered(UK_COUNT);
   for (int k = 0; k < UK_COUNT; ++k) {
@@ -214,6 +225,7 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
 
 bool user_rowsep(const UserModule* m) { return m && m->rowsep; }
 bool user_vector(const UserModule* m) { return m && m->vector; }
+bool user_fold(const UserModule* m) { return m && m->fold; }
 
 void jit_free(UserModule* m) {
   if (!m) return;
@@ -243,10 +255,14 @@ int ocs_problem_create_from_source(ocs_problem* out, const char* source, int nS,
   if (nS < 1 || nS > 64 || nC < 1 || nC > 8 || nparams < 0) return fail(OCS_ERR_SHAPE, "need 1 <= nS <= 64, 1 <= nC <= 8");
   std::string log;
   UserModule* m = nullptr;
-  const bool rowsep = (has_control_char & 2) != 0;   // flag word: bit 0 ocs_ControlChar present, bit 1 row functions
+  // flag word: bit 0 ocs_ControlChar present, bit 1 row functions, bit 2 (with both) ocs_ControlChar does not read x
+  // and ocs_row_dFdy does not read u
+  const bool rowsep = (has_control_char & 2) != 0;
+  if ((has_control_char & 4) && (has_control_char & 3) != 3)
+    return fail(OCS_ERR_INVALID, "flag bit 2 (ControlChar of the costate alone) needs row functions and ocs_ControlChar (bits 0 and 1)");
   if (rowsep && (nC != 1 || nparams > 16 || !(nS == 1 || nS == 2 || nS == 4)))
     return fail(OCS_ERR_SHAPE, "a problem given as row functions needs nC = 1, nS in {1, 2, 4} and at most 16 parameters");
-  const int rc = jit_build(source, nS, nC, nparams, (has_control_char & 1) != 0, true, &m, log, rowsep);
+  const int rc = jit_build(source, nS, nC, nparams, (has_control_char & 1) != 0, true, &m, log, rowsep, (has_control_char & 4) != 0);
   if (rc != OCS_OK) return fail(rc, "user problem: %s", log.substr(0, 400).c_str());
   ocs_problem_s* p = new ocs_problem_s();
   p->id = OCS_PROBLEM_USER;
@@ -270,7 +286,8 @@ int ocs_problem_check_source(const char* source, int nS, int nC, int nparams, in
   if (!source) return fail(OCS_ERR_INVALID, "null argument");
   std::string log;
   UserModule* m = nullptr;
-  const int rc = jit_build(source, nS, nC, nparams, (has_control_char & 1) != 0, false, &m, log, (has_control_char & 2) != 0);
+  const int rc = jit_build(source, nS, nC, nparams, (has_control_char & 1) != 0, false, &m, log, (has_control_char & 2) != 0,
+                           (has_control_char & 4) != 0);
   if (rc != OCS_OK) return fail(rc, "user problem: %s", log.substr(0, 400).c_str());
   jit_free(m);
   return OCS_OK;

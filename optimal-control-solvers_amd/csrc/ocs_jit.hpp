@@ -25,19 +25,22 @@ enum UserKernel : int {
   // problems given as the three full-vector methods (coupled rows, several controls), nS <= 4, nC <= 2: the vector-lane
   // state pass (ocs_pipelinev_kernel.hpp) and the scan adjoint pass with dense step maps (ocs_vscan_kernel.hpp)
   UK_FWD_PV_X, UK_FWD_PV_J, UK_VSCAN_LAM_DJDU, UK_VSCAN_LAM, UK_VSCAN_DJDU, UK_VSCAN_LAM_DJDU_LT, UK_VSCAN_LAM_LT, UK_VSCAN_DJDU_LT,
+  // row functions + ocs_ControlChar of the costate alone (OCS_USER_CC_NOX): the two kernels of fb_sweep's folded sweep
+  // (ocs_fold_kernel.hpp on a uniform / any grid, ocs_costate_scan_kernel.hpp with the convergence test)
+  UK_FWD_CC_UNI, UK_FWD_CC, UK_COSTATE_SCAN_MET,
   UK_COUNT
 };
 
 struct UserModule {
   int nS = 0, nC = 0, npar = 0, chunk = 4;
-  bool has_cc = false, loaded = false, rowsep = false, vector = false;
+  bool has_cc = false, loaded = false, rowsep = false, vector = false, fold = false;
   std::vector<char> code;
   hipModule_t mod = nullptr;
   hipFunction_t fn[UK_COUNT] = {};
 };
 
 int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool load, UserModule** out,
-              std::string& log, bool rowsep = false);
+              std::string& log, bool rowsep = false, bool ccnox = false);
 void jit_free(UserModule* m);
 int jit_launch(const UserModule* m, int kid, dim3 grid, dim3 block, void** params, hipStream_t s, unsigned shmem = 0);
 

@@ -1338,6 +1338,8 @@ int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const
 int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
                        const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
                        double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate) {
+  if (p.functor == Functor::User)   // hipRTC instance of the scan kernel (checks its own conditions)
+    return launch_costate_scan_met(p, g, batch, x, ldx, PR, lb, ub, relTol, absTol, sweep, status, maxChange, nactive, lam, s, gate);
   if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || !PR || !g.TU || !status || !maxChange || !nactive) return -1;
   if (costate_scan_ok(p, g, batch))
     return launch_costate_scan_met(p, g, batch, x, ldx, PR, lb, ub, relTol, absTol, sweep, status, maxChange, nactive, lam, s, gate);

@@ -144,6 +144,10 @@ struct LogisticK {
     a = __builtin_fma(-2.0, y, rp.m);
     b = ev * y;
   }
+  // the costate equation's row (compute_x_lam.m:11-14, lam_r' = -(a lam_r + b)) from the time coefficient e^{-r t}
+  __device__ static inline void costate_row_pre(double y, double tc, const RowPar& rp, double& a, double& b) {
+    row_dfdx_pre(y, 2.0 * tc, rp, a, b);
+  }
   // this row's share of (dF/du)' v:  -v_r + cw u ev,   cu = cw u
   __device__ static inline double row_dfdu(double cu, double v, double ev) {
     return __builtin_fma(cu, ev, -v);

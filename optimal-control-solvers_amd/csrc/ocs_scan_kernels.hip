@@ -122,8 +122,11 @@ bool costate_scan_ok(const ProblemDesc& p, const GridDesc& g, int batch) {
   // Selected while the chip has idle CUs (<= 128 workgroups): there the serial kernel's 1000-step chain sets the time
   // (measured, TestOCProblem, N = 1000, ms per solve of 12 sweeps, scan / serial: batch 2048 2.00 / 2.07, 4096 2.00 / 2.07,
   // 16 384 2.24 / 2.20 -- at BL-3's batch either pass moves its 24 B per instance-step at ~4.9 TB/s).
-  return !off && scan_supported(p.functor, p.nS, p.nC) && g.RECS && g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 &&
-         (on || batch / (64 / p.nS) <= 128);
+  const bool shape = g.RECS && g.N >= 8 && g.N % 8 == 0 && (p.nS == 1 || p.nS == 2 || p.nS == 4) && p.nC == 1 &&
+                     batch % (64 / p.nS) == 0;
+  // user problems that declare the costate equation free of u: the scan is their costate kernel at every batch
+  if (p.functor == Functor::User) return user_fold(p.user) && shape;
+  return !off && scan_supported(p.functor, p.nS, p.nC) && shape && (on || batch / (64 / p.nS) <= 128);
 }
 template <class P, bool MET>
 static void run_costate_scan(const CostateScanArgs& a, hipStream_t s) {
@@ -131,6 +134,11 @@ static void run_costate_scan(const CostateScanArgs& a, hipStream_t s) {
 }
 template <bool MET>
 static int launch_costate_scan_t(const ProblemDesc& p, const CostateScanArgs& a, hipStream_t s) {
+  if (p.functor == Functor::User) {
+    if (!MET) return -1;   // (only the sweep's costate pass is instantiated for user problems)
+    void* args[] = {(void*)&a};
+    return jit_launch(p.user, UK_COSTATE_SCAN_MET, dim3(a.batch / (64 / p.nS)), dim3(kScanW * 64), args, s);
+  }
   if (p.nS == 1)
     run_costate_scan<LogisticK<1>, MET>(a, s);
   else if (p.nS == 2)

@@ -14,6 +14,12 @@
 //   __device__ void ocs_ControlChar(double t, const double* x, const double* lam, OCS_PARAMS p,
 //                                   const double* lb, const double* ub, double* u);
 //
+//   (optional: #define OCS_USER_CC_TCOEF in the source and give
+//   __device__ double ocs_cc_tcoef(double t, OCS_PARAMS p);
+//    -- ocs_ControlChar then receives ocs_cc_tcoef(t, p) in the place of t, evaluated once per grid point into the
+//    integrator's tables instead of once per call: e.g. return exp(r t) for the current-value costate of a discounted
+//    problem, as the registry problems tabulate it.  The parameters it reads must be the same for all trajectories.)
+//
 // NS, NC, NPAR are available as constants.  OCS_PARAMS is `const double*` (a per-trajectory register copy,
 // so per-trajectory parameter overrides work) when NPAR <= 16, and a pointer to the shared parameter block
 // in constant address space (scalar loads) otherwise, and always for problems given as row functions.
@@ -36,6 +42,13 @@
 // (NC = 1.)  The full-vector plugin methods of OCProblem.m:8-21 are derived from them below, so every kernel works; in
 // addition the wave-specialised state pass and the scan adjoint pass (the mappings of the registry problems) are
 // instantiated for the problem.
+//
+// OCS_USER_CC_NOX (flag bit 2 of ocs_problem_create_from_source, with row functions and ocs_ControlChar): the problem
+// declares that ocs_ControlChar does not read x and that ocs_row_dFdy does not read u -- the minimum principle gives the
+// control from the costate alone and the costate equation does not see the control, as for a Hamiltonian that is
+// separable in (x, u).  fb_sweep then runs its two-kernel sweep (ocs_fold_kernel.hpp: the state pass forms its control
+// from the costate of the sweep before; ocs_costate_scan_kernel.hpp: the costate pass as a scan over time with the
+// convergence test inside).  ocs_ControlChar receives x = zeros and ocs_row_dFdy u = 0 there.
 #ifdef OCS_USER_ROWSEP
 __device__ static inline void ocs_F(double t, const double* y, const double* u, OCS_PARAMS p, double* f) {
   double s = 0.0;
@@ -68,7 +81,11 @@ __device__ static inline void ocs_dFdu_times_vec(double t, const double* y, cons
 namespace ocs {
 
 struct UserP {
+#if defined(OCS_USER_CC_NOX) && defined(OCS_USER_ROWSEP) && defined(OCS_USER_HAS_CONTROLCHAR)
+  static constexpr bool CC_READS_X = false;  // declared by the problem
+#else
   static constexpr bool CC_READS_X = true;   // unknown: ocs_ControlChar may read x
+#endif
   static constexpr int NS = OCS_USER_NS;
   static constexpr int NC = OCS_USER_NC;
   static constexpr int NAUG = OCS_USER_NS + 1;
@@ -104,7 +121,11 @@ struct UserP {
     (void)ps;
     tc[0] = t;
 #endif
+#ifdef OCS_USER_CC_TCOEF
+    tu[0] = ocs_cc_tcoef(t, (OCS_PARAMS)ps);    // the user's ControlChar-side time coefficient (shared parameters)
+#else
     tu[0] = t;
+#endif
   }
   __device__ static inline void step_consts(double, double, const double*, const double*, const double*, double*) {}
 
@@ -166,12 +187,32 @@ struct UserP {
     ocs_row_dFdu(st.t, y, u, par(rp.p), rp.r, &dF, &dq);
     return __builtin_fma(dF, v, dq * st.kc);
   }
+  // the costate equation's row: lam_r' = -(a lam_r + b), a = dF_r/dy_r, b = dq_r/dy_r (the cost row of [lam; 1]);
+  // only for problems that declare OCS_USER_CC_NOX (u is not read)
+  __device__ static inline void costate_row_pre(double y, double tc, const RowPar& rp, double& a, double& b) {
+    ocs_row_dFdy(tc, y, 0.0, par(rp.p), rp.r, &a, &b);
+  }
   // (names of the shifted form of the registry problems: never called, HAS_SHIFT is false)
   __device__ static inline double row_shift(const RowPar&) { return 0.0; }
   __device__ static inline double row_vertex(double, double u) { return u; }
   __device__ static inline double row_f_shifted(double z, double) { return z; }
   __device__ static inline double control_q(double, const RowPar&) { return 0.0; }
   __device__ static inline double state_q_acc(double, double acc) { return acc; }
+#endif
+
+#if defined(OCS_USER_CC_NOX) && defined(OCS_USER_ROWSEP) && defined(OCS_USER_HAS_CONTROLCHAR)
+  // ControlChar from the costate alone (the names LogisticK gives the same thing, ocs_problems.hpp)
+  struct CCPre {
+    Par p;
+  };
+  __device__ static inline CCPre cc_pre(const Par& p) { return CCPre{p}; }
+  __device__ static inline double control_char_pre(double tu, const double* lam, const CCPre& c, double lb, double ub) {
+    double x0[NS], u;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) x0[k] = 0.0;
+    ocs_ControlChar(tu, x0, lam, par(c.p), &lb, &ub, &u);
+    return u;
+  }
 #endif
 
   __device__ static inline void control_char(const double* tu, const double* x, const double* lam, const Par& p,

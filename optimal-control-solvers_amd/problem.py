@@ -92,10 +92,14 @@ class UserProblem(OCProblem):
     ocs_dFdx_times_vec, ocs_dFdu_times_vec, optionally ocs_ControlChar; contract in
     csrc/ocs_user_functor.hpp) and compiled with hipRTC for gfx950 when the object is created."""
 
-    def __init__(self, source, nS, nC, params, ControlBounds, has_control_char=False, row_separable=False):
+    def __init__(self, source, nS, nC, params, ControlBounds, has_control_char=False, row_separable=False,
+                 control_from_costate=False):
         """row_separable: the source defines ROW functions (ocs_row_F, ocs_row_q, ocs_row_dFdy, ocs_row_dFdu; contract in
         csrc/ocs_user_functor.hpp) instead of the three full-vector methods, which are derived from them; the problem
-        then also runs on the wave-specialised state pass and the scan adjoint pass (nC = 1, nS in {1, 2, 4})."""
+        then also runs on the wave-specialised state pass and the scan adjoint pass (nC = 1, nS in {1, 2, 4}).
+        control_from_costate (with row_separable and has_control_char): the problem declares that ocs_ControlChar does
+        not read x and ocs_row_dFdy does not read u; fb_sweep then runs its two-kernel sweep (state pass with the control
+        update folded in, costate pass as a scan with the convergence test) as for the registry problems."""
         self.nS, self.nC, self.nAug = int(nS), int(nC), int(nS) + 1
         self.params = _f(params).ravel()
         self.ControlBounds = _f(ControlBounds, (self.nC, 2))
@@ -103,14 +107,16 @@ class UserProblem(OCProblem):
         h = C.c_void_p()
         check(lib.ocs_problem_create_from_source(C.byref(h), source.encode(), self.nS, self.nC, _p(self.params),
                                                  self.params.size, _p(self.ControlBounds),
-                                                 int(bool(has_control_char)) | (2 if row_separable else 0)))
+                                                 int(bool(has_control_char)) | (2 if row_separable else 0) |
+                                                 (4 if control_from_costate else 0)))
         self._h = h
 
     @staticmethod
-    def check_source(source, nS, nC, nparams, has_control_char=False, row_separable=False):
+    def check_source(source, nS, nC, nparams, has_control_char=False, row_separable=False, control_from_costate=False):
         """Compile only (works without a GPU); raises OcsError with the compiler log on failure."""
         check(lib.ocs_problem_check_source(source.encode(), int(nS), int(nC), int(nparams),
-                                           int(bool(has_control_char)) | (2 if row_separable else 0)))
+                                           int(bool(has_control_char)) | (2 if row_separable else 0) |
+                                           (4 if control_from_costate else 0)))
 
 
 class TestOCProblem(OCProblem):

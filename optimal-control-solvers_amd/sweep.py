@@ -111,6 +111,12 @@ def fb_sweep_batch(prob, x0, tspan, options=None, integrator=None):
             "tspan": integ.tspan, "interpPts": interpPts}
 
 
+def fb_sweep_path(integrator):
+    """Diagnostic (ocs.h ocs_fb_sweep_path): the sweep loop the last fb_sweep on this integrator ran -- 1 kernel by kernel
+    as the reference sequences it, 2 fused control update, 3 windows, 4 the two-kernel sweep (fold)."""
+    return int(lib.ocs_fb_sweep_path(integrator._h))
+
+
 def fb_sweep(prob, x0, tspan, options=None):
     """soln = fb_sweep(prob, x0, tspan, options)   fb_sweep.m:1.  Returns a dict with the callables
     x, lam, u (pchip interpolants, vectorInterpolant.m) and J, or an empty dict when the sweep did not

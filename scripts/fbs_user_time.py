@@ -5,7 +5,7 @@ ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, 'tests'))
 import __graft_entry__ as g
 ocs = g.load_package()
-from user_problems import LOGISTIC2_SRC
+from user_problems import LOGISTIC2_SRC, LOGISTIC_ROWS_CC_SRC, LOGISTIC_ROWS_CCT_SRC
 dev = torch.device('cuda:0')
 rng = np.random.default_rng(3)
 batch, N = int(os.environ.get("BATCH", "4096")), 1000
@@ -13,7 +13,15 @@ x0 = torch.tensor(rng.uniform(0.8, 1.6, (2, batch)), device=dev)
 integ = ocs.RK4Integrator(ocs.linspace(0, 10, N + 1))
 reg = ocs.LogisticProblem([3.0, 2.5], 1.5, 0.05, [[0.0, 1.0]])
 usr = ocs.UserProblem(LOGISTIC2_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], [[0.0, 1.0]], has_control_char=True)
-for name, prob in (("registry", reg), ("user (hipRTC)", usr)):
+rows = ocs.UserProblem(LOGISTIC_ROWS_CC_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], [[0.0, 1.0]], has_control_char=True,
+                       row_separable=True)
+fold = ocs.UserProblem(LOGISTIC_ROWS_CC_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], [[0.0, 1.0]], has_control_char=True,
+                       row_separable=True, control_from_costate=True)
+foldt = ocs.UserProblem(LOGISTIC_ROWS_CCT_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], [[0.0, 1.0]], has_control_char=True,
+                        row_separable=True, control_from_costate=True)
+for name, prob in (("registry", reg), ("user (hipRTC, full-vector methods)", usr), ("user (hipRTC, row functions)", rows),
+                   ("user (hipRTC, row functions, control from costate)", fold),
+                   ("user (hipRTC, row functions, control from costate, ocs_cc_tcoef)", foldt)):
     for _ in range(2):
         r = ocs.fb_sweep_dev(prob, integ, x0)
     torch.cuda.synchronize(); t0 = time.perf_counter()

@@ -306,3 +306,49 @@ def test_vector_mappings_two_controls_and_three_states(ocs, oracle):
     ref2 = oracle.batch_states_adjoints(pob, ts2, x02, u2)
     assert relerr(x2, ref2["x"]) < RTOL and relerr(J2, ref2["J"]) < RTOL
     assert relerr(lam2, ref2["lam"]) < RTOL and relerr(d2, ref2["dJdu"]) < RTOL
+
+
+@pytest.mark.parametrize("nS,N,batch,grid,hoist", [(2, 1000, 64, "lin", False), (1, 160, 128, "lin", True),
+                                                   (4, 160, 32, "rand", False), (2, 96, 96, "np", True),
+                                                   (1, 1000, 192, "lin", False), (4, 200, 48, "np", True)])
+def test_fb_sweep_two_kernel_sweep_for_user_row_functions(ocs, oracle, nS, N, batch, grid, hoist):
+    """functions/fb_sweep.m:79-115 for a hipRTC problem given as row functions whose ocs_ControlChar reads the costate alone
+    (flag bit 2, control_from_costate): the two-kernel sweep of the registry problems (k_forward_cc: state pass forming its
+    control from the costate of the sweep before; k_costate_scan: costate pass as a scan with check_convergence inside),
+    instantiated with hipRTC.  Against the oracle per instance, against the same source without the declaration (the
+    kernel-by-kernel sequence) and against the registry problem of the same equations; uniform, numpy-linspace and
+    non-uniform grids, nS = 1, 2, 4, one to three workgroups; `hoist`: the source tabulates ControlChar's exponential
+    through ocs_cc_tcoef (OCS_USER_CC_TCOEF)."""
+    from tests.user_problems import LOGISTIC_ROWS_CC_SRC, LOGISTIC_ROWS_CCT_SRC
+    SRC = LOGISTIC_ROWS_CCT_SRC if hoist else LOGISTIC_ROWS_CC_SRC
+    c, r = 1.5, 0.05
+    m = [3.0, 2.5, 2.0, 3.5][:nS]
+    rng = np.random.default_rng(100 * nS + N)
+    T = 8.0
+    tspan = {"lin": oracle.linspace(0, T, N + 1), "np": np.linspace(0, T, N + 1),
+             "rand": np.concatenate([[0.0], np.sort(rng.uniform(0, T, N - 1)), [T]])}[grid]
+    if grid == "rand":   # keep the steps within a factor of the mean (the sweep has to converge on it)
+        tspan = 0.5 * (tspan + oracle.linspace(0, T, N + 1))
+    x0 = rng.uniform(0.8, 1.6, (nS, batch))
+    kw = dict(has_control_char=True, row_separable=True)
+    fold = ocs.UserProblem(SRC, nS, 1, [c, r] + m, BOUNDS, control_from_costate=True, **kw)
+    plain = ocs.UserProblem(SRC, nS, 1, [c, r] + m, BOUNDS, **kw)
+    reg = ocs.LogisticProblem(m, c, r, BOUNDS)
+    opts = {"nERROR_PTS": N + 1, "nINTERP_PTS": 81}
+    gf, gp, gr = (ocs.RK4Integrator(tspan) for _ in range(3))
+    sf = ocs.fb_sweep_batch(fold, x0, tspan, opts, integrator=gf)
+    sp = ocs.fb_sweep_batch(plain, x0, tspan, opts, integrator=gp)
+    sr = ocs.fb_sweep_batch(reg, x0, tspan, opts, integrator=gr)
+    on_nodes = grid != "rand"   # (error points = linspace: grid nodes only on an evenly spaced tspan)
+    assert ocs.fb_sweep_path(gf) == (4 if on_nodes else 1) and ocs.fb_sweep_path(gp) == 1
+    assert np.array_equal(sf["sweeps"], sp["sweeps"]) and np.array_equal(sf["sweeps"], sr["sweeps"])
+    ok = sf["sweeps"] > 0   # (with four states a few instances do not converge in 20 sweeps, on every path alike)
+    assert ok.mean() > 0.75 and (nS == 4 or ok.all())
+    for k, tol in (("J", 1e-11), ("x", 1e-10), ("lam", 1e-10), ("u", 1e-10)):
+        assert relerr(sf[k][..., ok], sp[k][..., ok]) < tol and relerr(sf[k][..., ok], sr[k][..., ok]) < tol, k
+    po = oracle.LogisticProblem(m, c, r, BOUNDS)
+    for b in [int(i) for i in np.flatnonzero(ok)[[0, ok.sum() // 3, -1]]]:
+        so = oracle.fb_sweep(po, x0[:, b], tspan, opts)
+        assert sf["sweeps"][b] == so["_sweeps"] and abs(sf["J"][b] - so["J"]) < 1e-10 * abs(so["J"])
+        assert relerr(sf["u"][:, :, b], so["u"]) < 1e-10 and relerr(sf["x"][:, :, b], so["x"]) < 1e-10
+        assert relerr(sf["lam"][:, :, b], so["lam"]) < 1e-10

@@ -42,6 +42,30 @@ __device__ void ocs_row_dFdu(double tc, double y, double u, OCS_PARAMS p, int r,
 }
 """
 
+# ... with the minimum-principle control of the same problem (the Gen-1 ControlChar of make_from_symbolic.m:33-38 for this
+# Hamiltonian): it reads the costate only, and ocs_row_dFdy above does not read u -> control_from_costate
+LOGISTIC_ROWS_CC_SRC = LOGISTIC_ROWS_SRC + r"""
+__device__ void ocs_ControlChar(double t, const double* x, const double* lam, OCS_PARAMS p, const double* lb,
+                                const double* ub, double* u) {
+  double s = lam[0];
+  for (int k = 1; k < NS; ++k) s += lam[k];
+  u[0] = fmin(ub[0], fmax(lb[0], s * exp(p[1] * t) / (2 * p[0])));
+}
+"""
+
+# ... and with the exponential of ControlChar hoisted into the integrator's tables (OCS_USER_CC_TCOEF: ocs_ControlChar
+# receives ocs_cc_tcoef(t, p) = e^{r t} in the place of t)
+LOGISTIC_ROWS_CCT_SRC = LOGISTIC_ROWS_SRC + r"""
+#define OCS_USER_CC_TCOEF 1
+__device__ double ocs_cc_tcoef(double t, OCS_PARAMS p) { return exp(p[1] * t); }
+__device__ void ocs_ControlChar(double ert, const double* x, const double* lam, OCS_PARAMS p, const double* lb,
+                                const double* ub, double* u) {
+  double s = lam[0];
+  for (int k = 1; k < NS; ++k) s += lam[k];
+  u[0] = fmin(ub[0], fmax(lb[0], s * ert / (2 * p[0])));
+}
+"""
+
 # a row-separable problem whose control enters multiplicatively (dF/du reads y): x_r' = x_r (m_r - x_r) - u x_r / (1 + r),
 # cost' = e^{-rt} (sum x_r^2 + c u^2);   params [c, r, m_1 .. m_NS]
 PROPHARVEST_ROWS_SRC = r"""
