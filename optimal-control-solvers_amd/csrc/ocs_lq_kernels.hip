@@ -21,6 +21,7 @@
 #include "ocs_device_common.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_rk4_kernels.hpp"
+#include <cstdlib>
 #ifdef OCS_LQ_STAMPS
 #include <cstdio>
 #include <vector>
@@ -1017,6 +1018,474 @@ __global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------
+// Mapping "M4": four waves per 16 trajectories (17 <= nS <= 32), the products split over K as well
+// ---------------------------------------------------------------------------------------
+// Wave (w, h) = (wave >> 1, wave & 1) of a 256-thread workgroup computes the PARTIAL product of row tile w over the
+// K half h (k-steps 4h .. 4h+3: four matrix instructions where a wave of M2 issues eight) and keeps the state rows of
+// tile h -- the B operand of exactly those k-steps -- up to date.  What goes through LDS is therefore not the stage
+// state (M2) but the partial products: every wave posts its 4 doubles per lane, one s_barrier, and wave (w, h) reads
+// and adds the two partials of tile h, P(h, 0) + P(h, 1) (the Bu u term rides in P(., 0)'s accumulator).  Both waves
+// that keep tile h form the same sums in the same order, so their copies of the state agree bit for bit.
+// A batch of 8192 puts two such waves (of different trajectory groups) on every SIMD: one group's exchange runs under
+// the other's matrix instructions; a batch of 1024 (the 8-GPU shard of BASELINE configs[4]) still spreads over 256
+// SIMDs with half the dependent matrix instructions per stage.
+// Adjoint pass: five exchanges per step -- (A Y2 | A'k4), A Y3, A'k3, A'k2, (A'k1 | A y_{i-1}); the contraction
+// Bu'(k2 + k3) of the midpoint column is done by the waves (0, h) and Bu'(k4 + k1) of the node column by the waves
+// (1, h) over the rows of their tile h, the two halves meet in the spare row of the last exchange.
+constexpr int kX4Row = 64, kX4Rows = 5, kX4Wave = kX4Rows * kX4Row, kX4Slot = 4 * kX4Wave;  // d2 units
+
+struct LQ4X {
+  d2* mine;
+  const d2* src;   // slot of wave (h, 0); wave (h, 1)'s follows it
+  int tog;
+  __device__ inline void init(d2* xb, int wv, int h, int lane) {
+    mine = xb + wv * kX4Wave + lane;
+    src = xb + (2 * h) * kX4Wave + lane;
+    tog = 0;
+  }
+  template <int NP, bool EXTRA>
+  __device__ inline void post(const d4 (&P)[NP], double e0 = 0.0, double e1 = 0.0) {
+    d2* p = mine + tog;
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      p[(2 * q) * kX4Row] = d2{P[q].x, P[q].y};
+      p[(2 * q + 1) * kX4Row] = d2{P[q].z, P[q].w};
+    }
+    if (EXTRA) p[4 * kX4Row] = d2{e0, e1};
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  // the sums of the two partials of this wave's tile; ex0 / ex1: the spare rows of waves (h, 0) and (h, 1)
+  template <int NP, bool EXTRA>
+  __device__ inline void fetch(d4 (&S)[NP], d2& ex0, d2& ex1) {
+    lq_lds_barrier();
+    const d2* p0 = src + tog;
+    const d2* p1 = p0 + kX4Wave;
+    d2 lo0[NP], hi0[NP], lo1[NP], hi1[NP];
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      lo0[q] = p0[(2 * q) * kX4Row];
+      hi0[q] = p0[(2 * q + 1) * kX4Row];
+      lo1[q] = p1[(2 * q) * kX4Row];
+      hi1[q] = p1[(2 * q + 1) * kX4Row];
+    }
+    if (EXTRA) {
+      ex0 = p0[4 * kX4Row];
+      ex1 = p1[4 * kX4Row];
+    }
+#pragma unroll
+    for (int q = 0; q < NP; ++q) S[q] = d4{lo0[q].x + lo1[q].x, lo0[q].y + lo1[q].y, hi0[q].x + hi1[q].x, hi0[q].y + hi1[q].y};
+    tog = kX4Slot - tog;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+};
+
+// four k-steps of one row tile: two accumulation chains
+__device__ static inline d4 mv4(const double (&Fr)[4], const double (&v)[4], d4 init) {
+  const d4 z = {0.0, 0.0, 0.0, 0.0};
+  d4 acc = mma(Fr[0], v[0], init);
+  d4 alt = mma(Fr[1], v[1], z);
+  acc = mma(Fr[2], v[2], acc);
+  alt = mma(Fr[3], v[3], alt);
+  return acc + alt;
+}
+__device__ static inline void d4_to(const d4 v, double (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
+
+template <bool FULL, bool OUT_X, bool UCONST>
+__global__ __launch_bounds__(256) void k_lq4_forward(const LQArgs a) {
+  using Rec = StepRec<1>;
+  __shared__ d2 xb[2 * kX4Slot];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), w = wv >> 1, h = wv & 1;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+  const int b0 = blockIdx.x * 16 + n;
+  const int b = b0 < a.batch ? b0 : a.batch - 1;
+  const size_t B = (size_t)a.batch;
+  const int nS = a.nS, nC = a.nC, N = a.N;
+  const size_t nAugB = (size_t)(nS + 1) * B;
+  LQ4X X;
+  X.init(xb, wv, h, lane);
+  const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+
+  double Aw[4], Bu, q[4], R;   // A[16w + n][4(4h + j) + g]; Bu[16w + n][g] (waves h == 0); q of the rows of tile h
+  {
+    const double* A = a.ps + 1;
+    const double* bu = A + (size_t)nS * nS;
+    const double* qq = bu + (size_t)nS * nC;
+    const int r = 16 * w + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * (4 * h + j) + g;
+      Aw[j] = (r < nS && c < nS) ? A[r + (size_t)nS * c] : 0.0;
+      q[j] = (16 * h + 4 * j + g < nS) ? qq[16 * h + 4 * j + g] : 0.0;
+    }
+    Bu = (r < nS && g < nC) ? bu[r + (size_t)nS * g] : 0.0;
+    R = (wv == 0 && g < nC) ? qq[nS + g] : 0.0;   // each control's cost is counted once
+  }
+  auto bu_times = [&](double u) OCS_INLINE { return h == 0 ? mma(Bu, u, z4) : z4; };   // (wave-uniform)
+  auto cost_part = [&](const double (&Y)[4], double u, double e) OCS_INLINE {
+    double s = R * (u * u);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) s = __builtin_fma(q[j], Y[j] * Y[j], s);
+    return e * s;
+  };
+  const bool costw = w == 0;   // the waves (0, h) integrate the objective over the rows of tile h
+
+  double y[4], yc = 0.0;   // rows 16h + 4j + g; yc: this wave's share of the running cost
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 16 * h + 4 * j + g;
+    y[j] = r < nS ? a.x0[(size_t)r * B + b] : 0.0;
+  }
+  double* xo = a.x + (size_t)(16 * h + g) * B + b;
+  const bool storew = w == 1;   // the waves (1, h) store the rows of tile h
+  if (OUT_X && storew) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (16 * h + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = y[j];
+  }
+  const bool uact = g < nC;
+  const size_t ustride = (size_t)nC * B;
+  const double* up = a.u + (size_t)(uact ? g : 0) * B + b;
+  double uA = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? *up : 0.0);
+  double uM = uA, uB = uA;
+  d4 buA = bu_times(uA), buM = buA, buB = buA;
+  double F1[4];
+  d2 e0, e1;
+  {  // stage 1 of step 0 (later steps: the exchange at the end of the step before)
+    d4 P[1] = {mv4(Aw, y, buA)}, S[1];
+    X.post<1, false>(P);
+    X.fetch<1, false>(S, e0, e1);
+    d4_to(S[0], F1);
+  }
+  double* xc = a.x + (size_t)nS * B + b;
+
+  struct Slot {
+    Rec r;
+    double uM, uB;
+  };
+  auto request = [&](int i, Slot& s) OCS_INLINE {
+    s.r = load_rec<1>(a.REC + (size_t)i * rec_stride(1));  // the table is padded past step N-1
+    if (!UCONST) {
+      const int ic = i < N ? i : N - 1;
+      const double* pu = up + (size_t)(2 * ic) * ustride;
+      s.uM = pu[ustride];
+      s.uB = pu[2 * ustride];
+    }
+  };
+  auto step = [&](int i, Slot& sl) OCS_INLINE {
+    const Rec cur = sl.r;
+    if (!UCONST) {
+      uM = uact ? sl.uM : 0.0;
+      uB = uact ? sl.uB : 0.0;
+    }
+    request(i + 2, sl);
+    if (!UCONST) {
+      buM = bu_times(uM);
+      buB = bu_times(uB);
+    }
+    double F2[4], F3[4], F4[4], Y[4];
+    double cs = 0.0;
+    d4 P[1], S[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y[j] = __builtin_fma(cur.hh, F1[j], y[j]);   // :40
+    P[0] = mv4(Aw, Y, buM);                                                   // :41
+    X.post<1, true>(P, yc, 0.0);   // ... with the wave's share of the running cost up to x(:, i)
+    if (costw) cs = cost_part(y, uA, cur.tcA[0]) + 2.0 * cost_part(Y, uM, cur.tcM[0]);
+    X.fetch<1, true>(S, e0, e1);
+    d4_to(S[0], F2);
+    const double ctot = e0.x + e1.x;   // wave 0: x(end, i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y[j] = __builtin_fma(cur.hh, F2[j], y[j]);   // :44
+    P[0] = mv4(Aw, Y, buM);                                                   // :45
+    X.post<1, false>(P);
+    if (costw) cs += 2.0 * cost_part(Y, uM, cur.tcM[0]);
+    X.fetch<1, false>(S, e0, e1);
+    d4_to(S[0], F3);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y[j] = __builtin_fma(cur.h, F3[j], y[j]);    // :48
+    P[0] = mv4(Aw, Y, buB);                                                   // :49
+    X.post<1, false>(P);
+    if (costw) cs += cost_part(Y, uB, cur.tcB[0]);
+    X.fetch<1, false>(S, e0, e1);
+    d4_to(S[0], F4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j)                                               // :50
+      y[j] = __builtin_fma(cur.h6, (F1[j] + 2.0 * F2[j]) + (2.0 * F3[j] + F4[j]), y[j]);
+    P[0] = mv4(Aw, y, buB);   // stage 1 of the next step   :37
+    X.post<1, false>(P);
+    if (costw) yc = __builtin_fma(cur.h6, sum_over_g(cs), yc);
+    if (OUT_X) {
+      if (wv == 0 && g == 0) xc[(size_t)i * nAugB] = ctot;
+      if (storew) {
+        xo += nAugB;
+        if (FULL) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) xo[(size_t)(4 * j) * B] = y[j];
+        } else {
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if (16 * h + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = y[j];
+        }
+      }
+    }
+    X.fetch<1, false>(S, e0, e1);
+    d4_to(S[0], F1);
+    uA = uB;
+    buA = buB;
+  };
+  Slot sa, sb;
+  request(0, sa);
+  request(1, sb);
+  int i = 0;
+  for (; i + 1 < N; i += 2) {
+    step(i, sa);
+    step(i + 1, sb);
+  }
+  if (i < N) step(i, sa);
+  {  // the two shares of the final cost
+    d4 P[1] = {z4}, S[1];
+    X.post<1, true>(P, yc, 0.0);
+    X.fetch<1, true>(S, e0, e1);
+    if (wv == 0 && g == 0) {
+      const double Jt = e0.x + e1.x;
+      if (OUT_X) xc[(size_t)N * nAugB] = Jt;
+      a.J[b] = a.Jadd ? a.Jadd[b] + Jt : Jt;  // J = x(end,end)   :55
+    }
+  }
+}
+
+template <bool FULL, bool OUT_LAM, bool OUT_DJDU, bool UCONST>
+__global__ __launch_bounds__(256) void k_lq4_backward(const LQArgs a) {
+  using Rec = StepRec<1>;
+  __shared__ d2 xb[2 * kX4Slot];
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), w = wv >> 1, h = wv & 1;
+  const int lane = threadIdx.x & 63, g = lane >> 4, n = lane & 15;
+  const int b0 = blockIdx.x * 16 + n;
+  const int b = b0 < a.batch ? b0 : a.batch - 1;
+  const size_t B = (size_t)a.batch;
+  const int nS = a.nS, nC = a.nC, N = a.N;
+  const size_t nAugB = (size_t)(nS + 1) * B;
+  LQ4X X;
+  X.init(xb, wv, h, lane);
+  const d4 z4 = {0.0, 0.0, 0.0, 0.0};
+
+  // A and A' fragments of (row tile w, K half h); Bu (waves h == 0); Bu' over the rows of tile h; q of tile h
+  double Aw[4], ATw[4], BuT[4], Bu, q[4];
+  {
+    const double* A = a.ps + 1;
+    const double* bu = A + (size_t)nS * nS;
+    const double* qq = bu + (size_t)nS * nC;
+    const int r = 16 * w + n;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int c = 4 * (4 * h + j) + g;
+      Aw[j] = (r < nS && c < nS) ? A[r + (size_t)nS * c] : 0.0;
+      ATw[j] = (r < nS && c < nS) ? A[c + (size_t)nS * r] : 0.0;
+      BuT[j] = (c < nS && n < nC) ? bu[c + (size_t)nS * n] : 0.0;
+      q[j] = (16 * h + 4 * j + g < nS) ? qq[16 * h + 4 * j + g] : 0.0;
+    }
+    Bu = (r < nS && g < nC) ? bu[r + (size_t)nS * g] : 0.0;
+  }
+  const double Rall = (g < nC) ? a.ps[1 + (size_t)nS * nS + (size_t)nS * nC + nS + g] : 0.0;
+  auto bu_times = [&](double u) OCS_INLINE { return h == 0 ? mma(Bu, u, z4) : z4; };
+  auto but_part = [&](const double (&v)[4]) OCS_INLINE {   // (Bu' v)_g over the rows of tile h
+    d4 acc = mma(BuT[0], v[0], z4), alt = mma(BuT[1], v[1], z4);
+    acc = mma(BuT[2], v[2], acc);
+    alt = mma(BuT[3], v[3], alt);
+    return acc.x + alt.x;
+  };
+  auto qy = [&](const double (&Y)[4], double e2kl, const d4 lin, double (&o)[4]) OCS_INLINE {   // :74 elementwise term
+    o[0] = __builtin_fma(q[0] * Y[0], e2kl, lin.x);
+    o[1] = __builtin_fma(q[1] * Y[1], e2kl, lin.y);
+    o[2] = __builtin_fma(q[2] * Y[2], e2kl, lin.z);
+    o[3] = __builtin_fma(q[3] * Y[3], e2kl, lin.w);
+  };
+
+  double lam[4], lamc;   // rows of tile h
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int r = 16 * h + 4 * j + g;
+    lam[j] = (a.lamT && r < nS) ? a.lamT[(size_t)r * B + b] : 0.0;
+  }
+  lamc = a.lamT ? a.lamT[(size_t)nS * B + b] : 1.0;
+  const bool storew = w == 1;   // the waves (1, h) store lam of tile h
+  double* lp = a.lam + (size_t)N * nAugB + (size_t)(16 * h + g) * B + b;
+  auto store_lam = [&]() OCS_INLINE {
+    if (!OUT_LAM) return;
+    if (storew) {
+      if (FULL) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) lp[(size_t)(4 * j) * B] = lam[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (16 * h + 4 * j + g < nS) lp[(size_t)(4 * j) * B] = lam[j];
+      }
+      if (wv == 2 && g == 0) lp[(size_t)nS * B] = lamc;   // (wave (1, 0), g = 0: lp points at row 0)
+    }
+    lp -= nAugB;
+  };
+  store_lam();
+
+  const bool uact = g < nC;
+  const size_t ustride = (size_t)nC * B;
+  const size_t uoff = (size_t)(uact ? g : 0) * B + b;
+  const double* up = a.u + uoff;
+  double* dq = a.dJdu + uoff;
+  double uB = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? up[(size_t)(2 * N) * ustride] : 0.0);
+  double uA = uB, uM = uB;
+  if (!UCONST) {
+    uA = uact ? up[(size_t)(2 * N - 2) * ustride] : 0.0;
+    uM = uact ? up[(size_t)(2 * N - 1) * ustride] : 0.0;
+  }
+  d4 buA = bu_times(uA), buM = bu_times(uM);
+  double k1c[4] = {0.0, 0.0, 0.0, 0.0}, k1lc = 0.0;
+
+  auto load_ck = [&](int i, double (&o)[4]) OCS_INLINE {
+    const double* c = a.xck + (size_t)i * nAugB + b;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int r = 16 * h + 4 * j + g;
+      o[j] = FULL ? c[(size_t)r * B] : ld_sel(c, (size_t)r * B, r < nS);
+    }
+  };
+  struct Slot {
+    Rec r;
+    double y[4];
+    double uA, uM;
+  };
+  auto request = [&](int i, Slot& s) OCS_INLINE {
+    s.r = load_rec<1>(a.REC + (long long)i * rec_stride(1));  // the table is padded before step 0
+    const int ic = i > 0 ? i : 0;
+    load_ck(ic, s.y);
+    if (!UCONST) {
+      s.uA = up[(size_t)(2 * ic) * ustride];
+      s.uM = up[(size_t)(2 * ic + 1) * ustride];
+    }
+  };
+  double yo[4], F[4];
+  double eA0 = 0.0;
+  d2 e0, e1;
+
+  auto step = [&](int i, Slot& sl, Slot& sn) OCS_INLINE {
+    const Rec cur = sl.r;
+    if (!UCONST) {
+      uA = uact ? sl.uA : 0.0;
+      uM = uact ? sl.uM : 0.0;
+    }
+    request(i - 2, sl);
+    const double k4l = cur.h6 * lamc, k3l = cur.h3 * lamc, k2l = k3l, k1l = k4l;
+    double k4[4], k3[4], k2[4], k1[4], g3[4], g2[4], g1[4], g0[4], Y2[4], Y3[4], Y4[4];
+    double pm = 0.0, pn = 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k4[j] = cur.h6 * lam[j];                                                            // :73
+      Y2[j] = __builtin_fma(cur.hh, F[j], yo[j]);
+    }
+    d4 P2[2], S2[2], P1[1], S1[1];
+    P2[0] = mv4(Aw, Y2, buM);     // recompute   A Y2
+    P2[1] = mv4(ATw, k4, z4);     // matrix part of A'k4   :74
+    X.post<2, false>(P2);
+    if (OUT_DJDU && w == 1) {     // node column over the rows of tile h   :108-112
+      double v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = k4[j] + k1c[j];
+      pn = but_part(v);
+    }
+    X.fetch<2, false>(S2, e0, e1);
+    d4_to(S2[0], F);
+    const d4 G3 = S2[1];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y3[j] = __builtin_fma(cur.hh, F[j], yo[j]);
+    P1[0] = mv4(Aw, Y3, buM);
+    X.post<1, false>(P1);
+    d4 buAn = buA, buMn = buM;
+    if (!UCONST) {
+      buAn = bu_times(uact ? sn.uA : 0.0);
+      buMn = bu_times(uact ? sn.uM : 0.0);
+    }
+    X.fetch<1, false>(S1, e0, e1);
+    d4_to(S1[0], F);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Y4[j] = __builtin_fma(cur.h, F[j], yo[j]);
+    qy(Y4, 2.0 * cur.tcB[0] * k4l, G3, g3);                                                // :74
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k3[j] = __builtin_fma(cur.h, g3[j], cur.h3 * lam[j]);      // :77
+    P1[0] = mv4(ATw, k3, z4);                                                              // :78
+    X.post<1, false>(P1);
+    X.fetch<1, false>(S1, e0, e1);
+    qy(Y3, 2.0 * cur.tcM[0] * k3l, S1[0], g2);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k2[j] = __builtin_fma(cur.hh, g2[j], cur.h3 * lam[j]);     // :81
+    P1[0] = mv4(ATw, k2, z4);                                                              // :82
+    X.post<1, false>(P1);
+    if (OUT_DJDU && w == 0) {     // midpoint column over the rows of tile h   :104-106
+      double v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = k2[j] + k3[j];
+      pm = but_part(v);
+    }
+    X.fetch<1, false>(S1, e0, e1);
+    qy(Y2, 2.0 * cur.tcM[0] * k2l, S1[0], g1);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k1[j] = __builtin_fma(cur.hh, g1[j], cur.h6 * lam[j]);     // :85
+    P2[0] = mv4(ATw, k1, z4);                                                              // :86-88
+    P2[1] = mv4(Aw, sn.y, buAn);  // stage 1 of step i-1 from its checkpoint
+    X.post<2, OUT_DJDU>(P2, w == 0 ? pm : pn, 0.0);
+    X.fetch<2, OUT_DJDU>(S2, e0, e1);
+    qy(yo, 2.0 * cur.tcA[0] * k1l, S2[0], g0);
+    d4_to(S2[1], F);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) lam[j] = (((lam[j] + g1[j]) + g2[j]) + g3[j]) + g0[j];
+    store_lam();
+    if (OUT_DJDU && uact) {
+      // wave 0 = (0, 0) has read the midpoint parts of the waves (0, 0), (0, 1); wave 3 = (1, 1) the node parts of (1, 0), (1, 1)
+      if (wv == 3) dq[(size_t)(2 * i + 2) * ustride] = (e0.x + e1.x) + 2.0 * cur.tcB[0] * Rall * uB * (k4l + k1lc);
+      if (wv == 0) dq[(size_t)(2 * i + 1) * ustride] = (e0.x + e1.x) + 2.0 * cur.tcM[0] * Rall * uM * (k2l + k3l);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      k1c[j] = k1[j];
+      yo[j] = sn.y[j];
+    }
+    k1lc = k1l;
+    eA0 = cur.tcA[0];
+    uB = uA;
+    buA = buAn;
+    buM = buMn;
+  };
+  Slot sa, sb;
+  request(N - 1, sa);
+  request(N - 2, sb);
+  {  // F1 of the first step (later steps: the last exchange of the step before)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) yo[j] = sa.y[j];
+    d4 P[1] = {mv4(Aw, sa.y, buA)}, S[1];
+    X.post<1, false>(P);
+    X.fetch<1, false>(S, e0, e1);
+    d4_to(S[0], F);
+  }
+  int i = N - 1;
+  for (; i >= 1; i -= 2) {
+    step(i, sa, sb);
+    step(i - 1, sb, sa);
+  }
+  if (i == 0) step(0, sa, sb);
+  if (OUT_DJDU) {  // first column: B(t_1, y_1, u_1)' k1_1   :100-101
+    const double p0 = w == 0 ? but_part(k1c) : 0.0;
+    d4 P[1] = {z4}, S[1];
+    X.post<1, true>(P, p0, 0.0);
+    X.fetch<1, true>(S, e0, e1);
+    if (wv == 0 && uact) dq[0] = (e0.x + e1.x) + 2.0 * eA0 * Rall * uB * k1lc;
+  }
+  if (a.lam0 && storew) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (16 * h + 4 * j + g < nS) a.lam0[(size_t)(16 * h + 4 * j + g) * B + b] = lam[j];
+    if (wv == 2 && g == 0) a.lam0[(size_t)nS * B + b] = lamc;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
 // plugin evaluation (ocs_problem_F / dFdx_times_vec / dFdu_times_vec): one thread per column
 // ---------------------------------------------------------------------------------------
 __global__ void k_lq_eval(int which, int k, int nS, int nC, const double* __restrict__ t,
@@ -1072,6 +1541,27 @@ static bool lq_two_wave(int batch, int mapping) {
   if (mapping == MAP_ROWSPLIT) return true;
   return batch <= 8192;  // beyond one wave per SIMD the single-wave mapping has less overhead
 }
+// four waves per 16 trajectories (K-split): OCS_LQ_MAP=4 always, =2 never (A/B timing); mapping request 3 forces it.
+// Automatic: while the four waves of a group still find SIMDs of their own (<= 4096 trajectories = 1024 waves).  Measured,
+// nS = 32, nC = 4, 2 x 4000 steps, ms state pass / adjoint pass, two waves -> four waves:
+//   batch 1024: 11.61 / 19.93 -> 11.02 / 18.08    2048: 11.61 / 19.99 -> 11.01 / 18.11    4096: 11.63 / 19.96 -> 11.12 / 18.26
+//   8192 (two waves of different groups per SIMD): 11.77 / 20.04 -> 16.80 / 32.88
+// A stage of M4 is 4 dependent matrix instructions + one LDS exchange of ~580 cycles that nothing of the same group can
+// run under (every partial product is needed before the post); a stage of M2 is 8 matrix instructions with the exchange
+// under the first four.  So M4 shortens the chain of a lone group by 5-9 % only, and two groups sharing a SIMD collide at
+// the barriers instead of interleaving.  What bounds BL-5 at batch 8192 is the dependent tail of each stage (result
+// latency of the last matrix instruction + the stage's vector update, ~200 of 730 cycles): with one independent wave per
+// SIMD there is nothing to fill it with; the one-wave mapping at batch 16 384 (no exchange, one wave per SIMD) runs the
+// adjoint pass at 58.6 TFLOP/s = 0.75 of the nominal peak.
+static bool lq_four_wave(int batch, int mapping) {
+  static const int env = [] {
+    const char* e = getenv("OCS_LQ_MAP");
+    return e ? atoi(e) : 0;
+  }();
+  if (mapping == MAP_LANE || mapping == MAP_ROWSPLIT || env == 2) return false;   // (MAP_ROWSPLIT: the two-wave mapping)
+  if (mapping == MAP_PIPELINE || env == 4) return true;
+  return batch <= 4096;
+}
 
 template <int RT>
 static void run_lq_forward(const LQArgs& a, bool uconst, hipStream_t s) {
@@ -1091,6 +1581,15 @@ int launch_forward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const 
   a.x0 = x0; a.u = u; a.x = x; a.J = J; a.Jadd = o.Jadd;
   if (p.nS <= 16) {
     run_lq_forward<1>(a, o.uconst, s);
+  } else if (lq_four_wave(batch, o.mapping)) {
+    const dim3 grid((batch + 15) / 16), block(256);
+    const bool fullp = p.nS == 32;
+    if (o.uconst)
+      fullp ? k_lq4_forward<true, true, true><<<grid, block, 0, s>>>(a) : k_lq4_forward<false, true, true><<<grid, block, 0, s>>>(a);
+    else if (a.x)
+      fullp ? k_lq4_forward<true, true, false><<<grid, block, 0, s>>>(a) : k_lq4_forward<false, true, false><<<grid, block, 0, s>>>(a);
+    else
+      fullp ? k_lq4_forward<true, false, false><<<grid, block, 0, s>>>(a) : k_lq4_forward<false, false, false><<<grid, block, 0, s>>>(a);
   } else if (lq_two_wave(batch, o.mapping)) {
     const dim3 grid((batch + 31) / 32), block(256);
 #ifdef OCS_LQ_STAMPS
@@ -1143,6 +1642,17 @@ int launch_backward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const
   a.xck = xck; a.u = u; a.lamT = lamT; a.lam = lam; a.dJdu = dJdu; a.lam0 = o.lam0;
   if (p.nS <= 16) {
     run_lq_backward<1>(a, o.uconst, s);
+  } else if (lq_four_wave(batch, o.mapping)) {
+    const dim3 grid((batch + 15) / 16), block(256);
+    const bool fullp = p.nS == 32;
+    if (o.uconst)
+      fullp ? k_lq4_backward<true, false, false, true><<<grid, block, 0, s>>>(a) : k_lq4_backward<false, false, false, true><<<grid, block, 0, s>>>(a);
+    else if (a.lam && a.dJdu)
+      fullp ? k_lq4_backward<true, true, true, false><<<grid, block, 0, s>>>(a) : k_lq4_backward<false, true, true, false><<<grid, block, 0, s>>>(a);
+    else if (a.lam)
+      fullp ? k_lq4_backward<true, true, false, false><<<grid, block, 0, s>>>(a) : k_lq4_backward<false, true, false, false><<<grid, block, 0, s>>>(a);
+    else
+      fullp ? k_lq4_backward<true, false, true, false><<<grid, block, 0, s>>>(a) : k_lq4_backward<false, false, true, false><<<grid, block, 0, s>>>(a);
   } else if (lq_two_wave(batch, o.mapping)) {
     const dim3 grid((batch + 31) / 32), block(256);
     const bool fullp = p.nS == 32;

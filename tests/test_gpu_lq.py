@@ -43,7 +43,7 @@ def test_plugin_methods(ocs, oracle, nS, nC):
     assert relerr(pg.dFdu_times_vec(t, y, u, v), po.dFdu_times_vec(t, y, u, v)) < 1e-13
 
 
-@pytest.mark.parametrize("mapping", [0, 1, 2])
+@pytest.mark.parametrize("mapping", [0, 1, 2, 3])
 @pytest.mark.parametrize("nS,nC,N,batch", [(1, 1, 7, 3), (5, 2, 33, 37), (16, 4, 64, 16), (17, 2, 20, 19), (20, 3, 50, 50),
                                            (32, 4, 96, 68), (32, 1, 3, 1)])
 def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch, mapping):
@@ -72,7 +72,7 @@ def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch, mapping):
         assert relerr(lam2[:, :, b], lamo) < RTOL and relerr(d2[:, :, b], do) < RTOL
 
 
-@pytest.mark.parametrize("mapping", [0, 1, 2])
+@pytest.mark.parametrize("mapping", [0, 1, 2, 3])
 def test_infinite_horizon_and_shooting_objective(ocs, oracle, mapping):
     """BL-5 shape at reduced size: nS = 32, nC = 4, RK4InfiniteIntegrator with uStar = 0, then the shooting objective
     (single_shooting.m:137-150) through a PWLinear basis with nC = 4 and a free initial state."""
