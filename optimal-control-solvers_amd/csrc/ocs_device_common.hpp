@@ -4,6 +4,17 @@
 
 namespace ocs {
 
+// The wave that carries a kernel's dependent chain (state / costate recursion) may ask the SIMD's arbiter for priority
+// over the helper waves it shares the SIMD with (OCS_CHAIN_PRIO: s_setprio level).  Off: measured with level 3 on the
+// headline pass pair and the folded sweep (scripts/ab_lib.sh) -- state pass 58.9-60.1 -> 60.0-60.7 us, sweep 177.7-178.6
+// -> 179.1-179.4 us: the chain waits for its own results (8 dependent fp64 operations per step), not for issue slots.
+#ifndef OCS_CHAIN_PRIO
+#define OCS_CHAIN_PRIO 0
+#endif
+__device__ static inline void chain_wave_priority() {
+  if (OCS_CHAIN_PRIO) __builtin_amdgcn_s_setprio(OCS_CHAIN_PRIO);
+}
+
 #define OCS_INLINE __attribute__((always_inline))
 
 // Wave-uniform read-only tables (step sizes, time coefficients, shared parameters) are read

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
     P2_END(wave);
   } else if (role == C_::S_) {
     // ---------------- S: the recursion (k_forward_p2's) ----------------
+    chain_wave_priority();
     const int r = lane / TPW, tl = lane % TPW, b = bw + tl;
     const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
     const bool fz = a.frozen != nullptr && a.frozen[b] != 0;

@@ -211,6 +211,7 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS, TPW_>::NWAVE * 64)) void k_forwa
     P2_END(0);
   } else if (wave == 1) {
     // ---------------- S: the recursion ----------------
+    chain_wave_priority();
     const int r = (lane / TPW) % G, tl = lane % TPW, b = bw + tl;   // (GS > G: the upper lane groups repeat the lower)
     const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
     const bool fz = FRZ && a.frozen != nullptr && a.frozen[b] != 0;

@@ -924,6 +924,7 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
     return;
   }
   // ---------------- L: costate recursion ----------------
+  chain_wave_priority();
   const int r = lane % G, tl = lane / G;
   const int b = bw + tl;
   const uniform_ptr PS = as_uniform(a.ps);
@@ -1248,6 +1249,7 @@ __global__ __launch_bounds__(MET ? 576 : 320) void k_costate_plx(const CostateXA
     return;
   }
   // ---------------- L: costate recursion ----------------
+  chain_wave_priority();
   const uniform_ptr PS = as_uniform(a.ps);
   const typename P::RowPar rp = P::load_row([&](int k) OCS_INLINE {
     return ((a.pmask >> k) & 1u) ? a.pb[(size_t)k * B + b] : PS[k];

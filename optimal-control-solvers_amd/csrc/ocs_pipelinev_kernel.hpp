@@ -94,6 +94,7 @@ __global__ __launch_bounds__((PVCfg<P::NS, P::NC>::NWAVE * 64)) void k_forward_p
     }
   } else if (wave == 1) {
     // ---------------- S: the recursion ----------------
+    chain_wave_priority();
     const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
     double y[NS], uprev[NC];
 #pragma unroll
