@@ -2,7 +2,9 @@
 // lam' = adjointRHS(t, x(t), lam, u(t)), lam(TF) = 0, integrated backwards; here RK4 on the node grid with x(t) the
 // pchip interpolant of the node values) as a scan over time, for row-separable problems whose adjoint
 // right-hand side does not read u: the registry's logistic family and hipRTC problems given as row functions that declare
-// it (OCS_USER_CC_NOX, ocs_user_functor.hpp).
+// it (OCS_USER_CC_NOX, ocs_user_functor.hpp).  UR: the same scan for ANY problem given as row functions -- the samples of
+// the control on the grid are read next to the state (8 more bytes per instance and step), dF_r/dy_r and dq_r/dy_r are
+// evaluated with them; the control update stays a kernel of its own (k_control_grid).
 //
 // adjointRHS = -dFdx_times_vec(t, [x; 0], u, [lam; 1])(1:nS) (the A9 adapter) is affine in lam, so an RK4
 // step from t_{i+1} down to t_i is an affine map per row, lam_i = alpha_i lam_{i+1} + beta_i, whose coefficients depend on
@@ -49,12 +51,15 @@ struct CostateScanArgs {
   int* status;
   double* maxChange;       // [nSWEEPS][B]
   int* nactive;
+  // UR
+  const double* u;         // [2N+1][B] samples of the control on the grid (nC = 1): problems whose adjoint right-hand side reads u
 };
 
-template <class P, int W, int L, bool MET>
+template <class P, int W, int L, bool MET, bool UR = false>
 __global__ __launch_bounds__(W * 64) void k_costate_scan(const CostateScanArgs a) {
   constexpr int G = P::NS, TPW = 64 / G;
   static_assert(P::NC == 1 && P::NTC == 1 && P::ROW_SEPARABLE && L == 4 && W * L + 1 <= kScanPadFront, "chunk shape");
+  static_assert(!(MET && UR), "the convergence test inside the pass is for problems whose control follows from the costate alone");
   __shared__ __attribute__((aligned(16))) double2 sm[2][W][64];               // chunk maps
   __shared__ double csm[2][64];                                                // lam at the bottom of a superblock
   __shared__ __attribute__((aligned(16))) double tab[2][W][2][128];            // per wave: records | interval records
@@ -106,6 +111,7 @@ __global__ __launch_bounds__(W * 64) void k_costate_scan(const CostateScanArgs a
     double w[L + 3];    // x(r, lo-1 .. lo+L+1), clamped to the grid
     double lo_[L];      // MET: the costate of the sweep before at nodes lo .. lo+L-1
     double tu[L];       // MET: ControlChar-side time coefficients of those nodes (wave-uniform: scalar loads)
+    double u[UR ? 2 * L + 1 : 1];   // UR: the control at grid points 2 lo .. 2 (lo + L)
   };
   const uniform_ptr TUu = as_uniform(a.TU);
 
@@ -128,6 +134,14 @@ __global__ __launch_bounds__(W * 64) void k_costate_scan(const CostateScanArgs a
         const int i = lo + q < 0 ? 0 : lo + q;
         d.lo_[q] = a.lam[(size_t)i * colB + (size_t)r * B + b];
         d.tu[q] = TUu[2 * i];
+      }
+    }
+    if (UR) {
+#pragma unroll
+      for (int t = 0; t < 2 * L + 1; ++t) {
+        int j = 2 * lo + t;
+        j = j < 0 ? 0 : (j > 2 * N ? 2 * N : j);
+        d.u[t] = a.u[(size_t)j * B + b];
       }
     }
   };
@@ -174,9 +188,15 @@ __global__ __launch_bounds__(W * 64) void k_costate_scan(const CostateScanArgs a
       const double xA = d.w[q + 1], xB = d.w[q + 2];
       const double xM = __builtin_fma(prs[q * kPRec + 11], dsl[q] - dsl[q + 1], 0.5 * (xA + xB));
       double aA, bA, aM, bM, aB, bB;
-      P::costate_row_pre(xA, eA, rp, aA, bA);
-      P::costate_row_pre(xM, eM, rp, aM, bM);
-      P::costate_row_pre(xB, eB, rp, aB, bB);
+      if constexpr (UR) {
+        P::costate_row_pre_u(xA, d.u[2 * q], eA, rp, aA, bA);
+        P::costate_row_pre_u(xM, d.u[2 * q + 1], eM, rp, aM, bM);
+        P::costate_row_pre_u(xB, d.u[2 * q + 2], eB, rp, aB, bB);
+      } else {
+        P::costate_row_pre(xA, eA, rp, aA, bA);
+        P::costate_row_pre(xM, eM, rp, aM, bM);
+        P::costate_row_pre(xB, eB, rp, aB, bB);
+      }
       // the RK4 step of k_costate_plx on the pair (coefficient of lam_{i+1}, constant):
       //   k1 = -(aB l + bB);  L = l - hh k1;  k2 = -(aM L + bM);  L = l - hh k2;  k3 = -(aM L + bM);  L = l - h k3;
       //   k4 = -(aA L + bA);  l <- l - h6 (k1 + 2 k2 + 2 k3 + k4)

@@ -79,6 +79,9 @@ int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const
                        const int* frozen, double* dump, double* lam, int ld, hipStream_t s, const int* gate = nullptr);
 // the same pass as a scan over time (ocs_costate_scan_kernel.hpp); _met: with the convergence test of the folded sweep
 bool costate_scan_ok(const ProblemDesc& p, const GridDesc& g, int batch);
+bool costate_scan_u_ok(const ProblemDesc& p, const GridDesc& g, int batch);
+int launch_costate_scan_u(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                          const double* u, const int* frozen, double* lam, hipStream_t s, const int* gate);
 int launch_costate_scan(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
                         const int* frozen, double* lam, hipStream_t s, const int* gate);
 int launch_costate_scan_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,

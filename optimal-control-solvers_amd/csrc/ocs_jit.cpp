@@ -92,6 +92,7 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep, bool f
     n[UK_SCAN_LAM_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", true, false, true, 0>";
     n[UK_SCAN_DJDU_LT] = "ocs::k_backward_scan<ocs::UserP, " + wl + ", false, true, true, 0>";
   }
+  if (rowsep) n[UK_COSTATE_SCAN_U] = "ocs::k_costate_scan<ocs::UserP, " + wl + ", false, true>";
   if (fold) {
     n[UK_FWD_CC_UNI] = "ocs::k_forward_cc<ocs::UserP, true>";
     n[UK_FWD_CC] = "ocs::k_forward_cc<ocs::UserP, false>";
@@ -134,7 +135,8 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   src += user_src;
   src += "\n#include \"ocs_user_functor.hpp\"\n#include \"ocs_rk4_kernels.hpp\"\n#include \"ocs_fbs_device.hpp\"\n";
   if (rowsep) src += "#include \"ocs_pipeline2_kernel.hpp\"\n#include \"ocs_scan_kernel.hpp\"\n";
-  if (fold) src += "#include \"ocs_fold_kernel.hpp\"\n#include \"ocs_costate_scan_kernel.hpp\"\n";
+  if (rowsep) src += "#include \"ocs_costate_scan_kernel.hpp\"\n";
+  if (fold) src += "#include \"ocs_fold_kernel.hpp\"\n";
   const bool vec = !rowsep && vector_shape_ok(nS, nC);
   if (vec) src += "#include \"ocs_pipelinev_kernel.hpp\"\n#include \"ocs_vscan_kernel.hpp\"\n";
 

@@ -28,6 +28,8 @@ enum UserKernel : int {
   // row functions + ocs_ControlChar of the costate alone (OCS_USER_CC_NOX): the two kernels of fb_sweep's folded sweep
   // (ocs_fold_kernel.hpp on a uniform / any grid, ocs_costate_scan_kernel.hpp with the convergence test)
   UK_FWD_CC_UNI, UK_FWD_CC, UK_COSTATE_SCAN_MET,
+  // any problem given as row functions: the costate pass of the sweep as a scan that reads the control samples
+  UK_COSTATE_SCAN_U,
   UK_COUNT
 };
 

@@ -148,6 +148,10 @@ struct LogisticK {
   __device__ static inline void costate_row_pre(double y, double tc, const RowPar& rp, double& a, double& b) {
     row_dfdx_pre(y, 2.0 * tc, rp, a, b);
   }
+  __device__ static inline void costate_row_pre_u(double y, double u, double tc, const RowPar& rp, double& a, double& b) {
+    (void)u;
+    row_dfdx_pre(y, 2.0 * tc, rp, a, b);
+  }
   // this row's share of (dF/du)' v:  -v_r + cw u ev,   cu = cw u
   __device__ static inline double row_dfdu(double cu, double v, double ev) {
     return __builtin_fma(cu, ev, -v);

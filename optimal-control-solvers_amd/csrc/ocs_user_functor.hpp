@@ -188,9 +188,12 @@ struct UserP {
     return __builtin_fma(dF, v, dq * st.kc);
   }
   // the costate equation's row: lam_r' = -(a lam_r + b), a = dF_r/dy_r, b = dq_r/dy_r (the cost row of [lam; 1]);
-  // only for problems that declare OCS_USER_CC_NOX (u is not read)
+  // without u only for problems that declare OCS_USER_CC_NOX (u is not read)
   __device__ static inline void costate_row_pre(double y, double tc, const RowPar& rp, double& a, double& b) {
     ocs_row_dFdy(tc, y, 0.0, par(rp.p), rp.r, &a, &b);
+  }
+  __device__ static inline void costate_row_pre_u(double y, double u, double tc, const RowPar& rp, double& a, double& b) {
+    ocs_row_dFdy(tc, y, u, par(rp.p), rp.r, &a, &b);
   }
   // (names of the shifted form of the registry problems: never called, HAS_SHIFT is false)
   __device__ static inline double row_shift(const RowPar&) { return 0.0; }
@@ -200,8 +203,9 @@ struct UserP {
   __device__ static inline double state_q_acc(double, double acc) { return acc; }
 #endif
 
-#if defined(OCS_USER_CC_NOX) && defined(OCS_USER_ROWSEP) && defined(OCS_USER_HAS_CONTROLCHAR)
-  // ControlChar from the costate alone (the names LogisticK gives the same thing, ocs_problems.hpp)
+#if defined(OCS_USER_ROWSEP)
+  // ControlChar from the costate alone (the names LogisticK gives the same thing, ocs_problems.hpp); only called by the
+  // kernels of the two-kernel sweep, which are instantiated for problems that declare OCS_USER_CC_NOX
   struct CCPre {
     Par p;
   };
@@ -210,7 +214,12 @@ struct UserP {
     double x0[NS], u;
 #pragma unroll
     for (int k = 0; k < NS; ++k) x0[k] = 0.0;
+#ifdef OCS_USER_HAS_CONTROLCHAR
     ocs_ControlChar(tu, x0, lam, par(c.p), &lb, &ub, &u);
+#else
+    (void)tu; (void)lam; (void)c; (void)ub;
+    u = lb;
+#endif
     return u;
   }
 #endif

@@ -340,7 +340,9 @@ def test_fb_sweep_two_kernel_sweep_for_user_row_functions(ocs, oracle, nS, N, ba
     sp = ocs.fb_sweep_batch(plain, x0, tspan, opts, integrator=gp)
     sr = ocs.fb_sweep_batch(reg, x0, tspan, opts, integrator=gr)
     on_nodes = grid != "rand"   # (error points = linspace: grid nodes only on an evenly spaced tspan)
-    assert ocs.fb_sweep_path(gf) == (4 if on_nodes else 1) and ocs.fb_sweep_path(gp) == 1
+    # (without the declaration: state pass, costate scan that reads the control samples, ControlChar on the grid, bookkeeping,
+    #  enqueued one sweep ahead)
+    assert ocs.fb_sweep_path(gf) == (4 if on_nodes else 1) and ocs.fb_sweep_path(gp) == (2 if on_nodes else 1)
     assert np.array_equal(sf["sweeps"], sp["sweeps"]) and np.array_equal(sf["sweeps"], sr["sweeps"])
     ok = sf["sweeps"] > 0   # (with four states a few instances do not converge in 20 sweeps, on every path alike)
     assert ok.mean() > 0.75 and (nS == 4 or ok.all())
@@ -352,3 +354,30 @@ def test_fb_sweep_two_kernel_sweep_for_user_row_functions(ocs, oracle, nS, N, ba
         assert sf["sweeps"][b] == so["_sweeps"] and abs(sf["J"][b] - so["J"]) < 1e-10 * abs(so["J"])
         assert relerr(sf["u"][:, :, b], so["u"]) < 1e-10 and relerr(sf["x"][:, :, b], so["x"]) < 1e-10
         assert relerr(sf["lam"][:, :, b], so["lam"]) < 1e-10
+
+
+@pytest.mark.parametrize("nS,N,batch", [(2, 400, 64), (1, 96, 192), (4, 160, 48)])
+def test_fb_sweep_row_functions_whose_adjoint_reads_the_control(ocs, oracle, nS, N, batch):
+    """fb_sweep.m:79-115 for a problem given as row functions whose ControlChar reads x and whose dF/dy reads u (proportional
+    harvest): the costate pass runs as the scan that reads the control samples (k_costate_scan<.., UR>), the sweeps are
+    enqueued one ahead.  Against the kernel-by-kernel sequence of the same library on the lane kernels (fused_update_off = 1:
+    lane-per-instance costate kernel, pchip midpoints and ControlChar in their own kernels, one host round trip per sweep)."""
+    from tests.user_problems import PROPHARVEST_ROWS_CC_SRC
+    c, r = 3.0, 0.05
+    m = [3.0, 2.5, 2.0, 3.5][:nS]
+    rng = np.random.default_rng(7 * nS + N)
+    tspan = oracle.linspace(0, 5.0, N + 1)   # (grid helper only)
+    x0 = rng.uniform(0.8, 1.6, (nS, batch))
+    pu = ocs.UserProblem(PROPHARVEST_ROWS_CC_SRC, nS, 1, [c, r] + m, [[0.0, 1.0]], has_control_char=True, row_separable=True)
+    # (the plain iteration u <- ControlChar oscillates on this problem: damped update, ocs.h uRelax)
+    opts = {"nERROR_PTS": N + 1, "nINTERP_PTS": 61, "uRelax": 0.5, "nSWEEPS": 100}
+    ga, gb = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
+    sa = ocs.fb_sweep_batch(pu, x0, tspan, opts, integrator=ga)
+    sb = ocs.fb_sweep_batch(pu, x0, tspan, dict(opts, fused_update_off=1), integrator=gb)
+    assert ocs.fb_sweep_path(ga) == 2 and ocs.fb_sweep_path(gb) == 1
+    print("sweeps", np.unique(sa["sweeps"], return_counts=True), "max u", float(sa["u"].max()))
+    assert np.array_equal(sa["sweeps"], sb["sweeps"]) and (sa["sweeps"] > 0).mean() > 0.9
+    ok = sa["sweeps"] > 0
+    for k, tol in (("J", 1e-11), ("x", 1e-10), ("lam", 1e-10), ("u", 1e-10)):
+        assert relerr(sa[k][..., ok], sb[k][..., ok]) < tol, k
+    assert np.all(sa["u"][..., ok].max(axis=(0, 1)) > 0.02)   # the control is not stuck at its lower bound

@@ -84,6 +84,16 @@ __device__ void ocs_row_dFdu(double tc, double y, double u, OCS_PARAMS p, int r,
 }
 """
 
+# ... with its minimum-principle control, which reads x (and ocs_row_dFdy above reads u): no control_from_costate
+PROPHARVEST_ROWS_CC_SRC = PROPHARVEST_ROWS_SRC + r"""
+__device__ void ocs_ControlChar(double t, const double* x, const double* lam, OCS_PARAMS p, const double* lb,
+                                const double* ub, double* u) {
+  double s = 0.0;
+  for (int k = 0; k < NS; ++k) s += lam[k] * x[k] / (1 + k);
+  u[0] = fmin(ub[0], fmax(lb[0], s * exp(p[1] * t) / (2 * p[0])));
+}
+"""
+
 
 class PropHarvestNP:
     """NumPy twin of PROPHARVEST_ROWS_SRC with the OCProblem method signatures (columns vectorised)."""
