@@ -43,9 +43,12 @@ int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const dou
 
 // whether launch_costate takes xmid == NULL (with PR) and forms the pchip midpoints of x itself
 bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch) {
-  if (p.functor == Functor::User)   // problems given as row functions: the scan that reads the control samples
+  if (p.functor == Functor::User) {
+    if (user_vector(p.user)) return N >= 8 && N % 8 == 0;   // full-vector methods, nS <= 4, nC <= 2: dense step maps
+    // problems given as row functions: the scan that reads the control samples
     return user_rowsep(p.user) && p.nC == 1 && (p.nS == 1 || p.nS == 2 || p.nS == 4) && N >= 8 && N % 8 == 0 &&
            batch % (64 / p.nS) == 0;
+  }
   return costate_pl_ok(p.functor, p.nS, p.nC, N, batch) && batch / (64 / p.nS) <= 512;
 }
 template <class P>
@@ -56,8 +59,11 @@ int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const dou
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb,
                    const double* PR, const int* gate) {
   if (frozen && !dump) return -1;
-  if (p.functor == Functor::User && !xmid)
-    return (ldb == 0 || ldb == batch) ? launch_costate_scan_u(p, g, batch, x, ldx, PR, u, frozen, lam, s, gate) : -1;
+  if (p.functor == Functor::User && !xmid) {
+    if (ldb != 0 && ldb != batch) return -1;
+    return user_vector(p.user) ? launch_costate_vscan(p, g, batch, x, ldx, PR, u, frozen, lam, s, gate)
+                               : launch_costate_scan_u(p, g, batch, x, ldx, PR, u, frozen, lam, s, gate);
+  }
   // the wave-specialised kernel while its workgroups (one per 64/nS instances) fit on the chip in two rounds
   if (p.functor != Functor::User && costate_forms_midpoints(p, g.N, batch))
     return xmid ? launch_costate_pl(p, g, batch, x, ldx, xmid, frozen, dump, lam, ldb, s)

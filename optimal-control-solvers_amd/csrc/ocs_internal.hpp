@@ -54,7 +54,7 @@ bool user_vector(const UserModule* m);
 bool user_fold(const UserModule* m);
 bool vector_problem_ok(const ProblemDesc& p);
 int launch_forward_pv(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u, double* x,
-                      double* J, hipStream_t s, bool no_cost_row, const int* gate);
+                      double* J, hipStream_t s, bool no_cost_row, const int* gate, const int* frozen = nullptr);
 int launch_backward_vscan(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                           const double* lamT, double* lam, double* dJdu, double* lam0, const double* pend0,
                           hipStream_t s);
@@ -80,6 +80,10 @@ int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const
 // the same pass as a scan over time (ocs_costate_scan_kernel.hpp); _met: with the convergence test of the folded sweep
 bool costate_scan_ok(const ProblemDesc& p, const GridDesc& g, int batch);
 bool costate_scan_u_ok(const ProblemDesc& p, const GridDesc& g, int batch);
+// any user problem with nS <= 4, nC <= 2 given as full-vector methods: the costate pass as a scan with dense step maps
+bool costate_vscan_ok(const ProblemDesc& p, const GridDesc& g, int batch);
+int launch_costate_vscan(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                         const double* u, const int* frozen, double* lam, hipStream_t s, const int* gate);
 int launch_costate_scan_u(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
                           const double* u, const int* frozen, double* lam, hipStream_t s, const int* gate);
 int launch_costate_scan(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,

@@ -108,6 +108,7 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep, bool f
     n[UK_VSCAN_LAM_DJDU_LT] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", true, true, true>";
     n[UK_VSCAN_LAM_LT] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", true, false, true>";
     n[UK_VSCAN_DJDU_LT] = "ocs::k_backward_vscan<ocs::UserP, " + vw + ", false, true, true>";
+    n[UK_COSTATE_VSCAN] = "ocs::k_costate_vscan<ocs::UserP, " + vw + ">";
   }
   return n;
 }
@@ -138,18 +139,18 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   if (rowsep) src += "#include \"ocs_costate_scan_kernel.hpp\"\n";
   if (fold) src += "#include \"ocs_fold_kernel.hpp\"\n";
   const bool vec = !rowsep && vector_shape_ok(nS, nC);
-  if (vec) src += "#include \"ocs_pipelinev_kernel.hpp\"\n#include \"ocs_vscan_kernel.hpp\"\n";
+  if (vec) src += "#include \"ocs_pipelinev_kernel.hpp\"\n#include \"ocs_vscan_kernel.hpp\"\n#include \"ocs_costate_vscan_kernel.hpp\"\n";
 
   const char* hdr_src[] = {src_ocs_device_common_hpp, src_ocs_user_functor_hpp, src_ocs_rk4_kernels_hpp,
                            src_ocs_fbs_device_hpp, src_ocs_pipeline2_kernel_hpp, src_ocs_scan_kernel_hpp,
                            src_ocs_pipelinev_kernel_hpp, src_ocs_vscan_kernel_hpp, src_ocs_fold_kernel_hpp,
-                           src_ocs_costate_scan_kernel_hpp};
+                           src_ocs_costate_scan_kernel_hpp, src_ocs_costate_vscan_kernel_hpp};
   const char* hdr_name[] = {"ocs_device_common.hpp", "ocs_user_functor.hpp", "ocs_rk4_kernels.hpp",
                             "ocs_fbs_device.hpp", "ocs_pipeline2_kernel.hpp", "ocs_scan_kernel.hpp",
                             "ocs_pipelinev_kernel.hpp", "ocs_vscan_kernel.hpp", "ocs_fold_kernel.hpp",
-                            "ocs_costate_scan_kernel.hpp"};
+                            "ocs_costate_scan_kernel.hpp", "ocs_costate_vscan_kernel.hpp"};
   hiprtcProgram prog = nullptr;
-  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 10, hdr_src, hdr_name) != 0) {
+  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 11, hdr_src, hdr_name) != 0) {
     log = "hiprtcCreateProgram failed";
     return OCS_ERR_HIP;
   }

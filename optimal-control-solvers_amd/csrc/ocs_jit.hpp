@@ -30,6 +30,8 @@ enum UserKernel : int {
   UK_FWD_CC_UNI, UK_FWD_CC, UK_COSTATE_SCAN_MET,
   // any problem given as row functions: the costate pass of the sweep as a scan that reads the control samples
   UK_COSTATE_SCAN_U,
+  // full-vector problems with nS <= 4, nC <= 2: the costate pass of the sweep as a scan with dense step maps
+  UK_COSTATE_VSCAN,
   UK_COUNT
 };
 

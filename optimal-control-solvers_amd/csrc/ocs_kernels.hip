@@ -199,7 +199,7 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
   // (MAP_SCAN names the adjoint kernel; the state pass of such an integrator is chosen automatically)
   int map = choose_mapping(p, g.N, batch, o.mapping == MAP_SCAN ? MAP_AUTO : o.mapping, plain, false, x != nullptr);
   if (map == MAP_ROWSPLIT && (o.frozen || o.ld) && o.mapping == MAP_AUTO) map = MAP_LANE;  // not in that kernel
-  if (map == MAP_PIPELINE && forward_is_vector(p) && (o.frozen || o.ld) && o.mapping == MAP_AUTO) map = MAP_LANE;
+  if (map == MAP_PIPELINE && forward_is_vector(p) && o.ld && o.mapping == MAP_AUTO) map = MAP_LANE;
   if (map == MAP_PIPELINE) {
     const int N1 = plain ? pipeline_steps(p, g.N, batch, false) : 0;
     if (N1 == 0 || (N1 < g.N && !x)) return -1;  // the split needs the boundary column in memory
@@ -208,8 +208,8 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
     // (a split pass hands the running objective to the lane kernel through the boundary column: keep the row then)
     int rc;
     if (forward_is_vector(p)) {
-      if (o.frozen || o.ld) return -1;
-      rc = launch_forward_pv(p, g1, batch, x0, u, x, J, s, o.no_cost_row && N1 == g.N, o.gate);
+      if (o.ld) return -1;
+      rc = launch_forward_pv(p, g1, batch, x0, u, x, J, s, o.no_cost_row && N1 == g.N, o.gate, o.frozen);
     } else {
       rc = launch_forward_pl(p, g1, batch, x0, u, x, J, o.frozen, o.dump, o.ld, s, o.no_cost_row && N1 == g.N, o.gate);
     }

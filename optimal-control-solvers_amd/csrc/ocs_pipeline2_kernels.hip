@@ -35,9 +35,9 @@ static void run_forward_pv(const FwdArgsP2& a, hipStream_t s) {
     k_forward_pv<P, false><<<grid, block, 0, s>>>(a);
 }
 int launch_forward_pv(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u, double* x,
-                      double* J, hipStream_t s, bool no_cost_row, const int* gate) {
+                      double* J, hipStream_t s, bool no_cost_row, const int* gate, const int* frozen) {
   if (!vector_problem_ok(p) || g.N < 8 || g.N % 8 != 0 || batch < 64 || batch % 64 != 0) return -1;
-  const FwdArgsP2 a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, 0, no_cost_row ? 1 : 0, gate};
+  const FwdArgsP2 a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, frozen, 0, no_cost_row ? 1 : 0, gate};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, x ? UK_FWD_PV_X : UK_FWD_PV_J, dim3(batch / 64), dim3(kPvWaves * 64), args, s);

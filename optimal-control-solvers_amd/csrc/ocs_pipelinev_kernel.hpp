@@ -140,7 +140,7 @@ __global__ __launch_bounds__((PVCfg<P::NS, P::NC>::NWAVE * 64)) void k_forward_p
         }
       }
     }
-    if (OUT_X && valid) {
+    if (OUT_X && valid && !(a.frozen != nullptr && a.frozen[b] != 0)) {
 #pragma unroll
       for (int r = 0; r < NS; ++r) a.x[((size_t)a.N * NAUG + r) * B + b] = y[r];   // x(t_N); the other nodes come from C
     }
@@ -149,7 +149,8 @@ __global__ __launch_bounds__((PVCfg<P::NS, P::NC>::NWAVE * 64)) void k_forward_p
     const int cw = wave - 2;
     const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
     const unsigned B8 = (unsigned)(B * 8), col8 = (unsigned)(colB * 8);
-    const unsigned vx = valid ? (unsigned)((size_t)b * 8) : kDropP2;
+    const bool fz = a.frozen != nullptr && a.frozen[b] != 0;   // (fb_sweep: a converged instance stores nothing)
+    const unsigned vx = (valid && !fz) ? (unsigned)((size_t)b * 8) : kDropP2;
     int cC = 0;
     for (int k = -1; k <= nb + 1; ++k) {
       lds_barrier_p2_();
@@ -195,10 +196,11 @@ __global__ __launch_bounds__((PVCfg<P::NS, P::NC>::NWAVE * 64)) void k_forward_p
   } else {
     // ---------------- J: running objective ----------------
     const bool wc = OUT_X && !a.nocost;
+    const bool fz = a.frozen != nullptr && a.frozen[b] != 0;
     const unsigned col8 = (unsigned)(colB * 8);
-    const unsigned vj = (valid && wc) ? (unsigned)(((size_t)NS * B + b) * 8) + col8 : kDropP2;
+    const unsigned vj = (valid && wc && !fz) ? (unsigned)(((size_t)NS * B + b) * 8) + col8 : kDropP2;
     double carry = 0.0;
-    if (wc && valid) a.x[(size_t)NS * B + b] = 0.0;
+    if (wc && valid && !fz) a.x[(size_t)NS * B + b] = 0.0;
     for (int k = -1; k <= nb + 1; ++k) {
       lds_barrier_p2_();
       if (k >= 2) {
@@ -211,7 +213,7 @@ __global__ __launch_bounds__((PVCfg<P::NS, P::NC>::NWAVE * 64)) void k_forward_p
         }
       }
     }
-    if (valid) a.J[b] = carry;
+    if (valid && !fz) a.J[b] = carry;
   }
 }
 

@@ -169,6 +169,19 @@ int launch_costate_scan_u(const ProblemDesc& p, const GridDesc& g, int batch, co
   void* args[] = {(void*)&a};
   return jit_launch(p.user, UK_COSTATE_SCAN_U, dim3(batch / (64 / p.nS)), dim3(kScanW * 64), args, s);
 }
+// any user problem given as full-vector methods, nS <= 4, nC <= 2 (hipRTC instance of k_costate_vscan)
+bool costate_vscan_ok(const ProblemDesc& p, const GridDesc& g, int batch) {
+  return p.functor == Functor::User && user_vector(p.user) && g.RECS && g.N >= 8 && g.N % 8 == 0 && batch >= 1;
+}
+int launch_costate_vscan(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
+                         const double* u, const int* frozen, double* lam, hipStream_t s, const int* gate) {
+  if (!costate_vscan_ok(p, g, batch) || !PR || !u) return -1;
+  CostateScanArgs a{};
+  a.N = g.N; a.batch = batch; a.RECS = g.RECS; a.PR = PR; a.ps = p.ps; a.pb = p.pb; a.pmask = p.pmask;
+  a.x = x; a.ldx = ldx; a.frozen = frozen; a.lam = lam; a.gate = gate; a.u = u;
+  void* args[] = {(void*)&a};
+  return jit_launch(p.user, UK_COSTATE_VSCAN, dim3((batch + 63) / 64), dim3(vscan_waves(p.nS) * 64), args, s);
+}
 int launch_costate_scan_met(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
                             const double* lb, const double* ub, double relTol, double absTol, int sweep, int* status,
                             double* maxChange, int* nactive, double* lam, hipStream_t s, const int* gate) {

@@ -381,3 +381,31 @@ def test_fb_sweep_row_functions_whose_adjoint_reads_the_control(ocs, oracle, nS,
     for k, tol in (("J", 1e-11), ("x", 1e-10), ("lam", 1e-10), ("u", 1e-10)):
         assert relerr(sa[k][..., ok], sb[k][..., ok]) < tol, k
     assert np.all(sa["u"][..., ok].max(axis=(0, 1)) > 0.02)   # the control is not stuck at its lower bound
+
+
+@pytest.mark.parametrize("N,batch,grid", [(200, 128, "lin"), (1000, 64, "lin"), (96, 70, "np"), (104, 192, "np")])
+def test_fb_sweep_full_vector_plugin_on_the_vector_mappings(ocs, oracle, N, batch, grid):
+    """fb_sweep.m:79-115 for a plugin given as the three full-vector methods + ocs_ControlChar (no row structure declared):
+    vector-lane state pass with the frozen / gate arguments (k_forward_pv), costate pass as a scan with dense step maps
+    (k_costate_vscan: pchip midpoints of x formed inside, control samples read), ControlChar on the grid, bookkeeping; sweeps
+    enqueued one ahead where the batch is whole tiles (path 2), else kernel by kernel with the same costate kernel (path 1).
+    Per instance against the oracle and the registry problem of the same equations."""
+    c, r, m = 1.5, 0.05, [3.0, 2.5]
+    rng = np.random.default_rng(N + batch)
+    tspan = oracle.linspace(0, 8.0, N + 1) if grid == "lin" else np.linspace(0, 8.0, N + 1)
+    x0 = rng.uniform(0.8, 1.6, (2, batch))
+    pu = ocs.UserProblem(LOGISTIC2_SRC, 2, 1, [c, r] + m, BOUNDS, has_control_char=True)
+    reg = ocs.LogisticProblem(m, c, r, BOUNDS)
+    opts = {"nERROR_PTS": N + 1, "nINTERP_PTS": 81}
+    gu, gr = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
+    su = ocs.fb_sweep_batch(pu, x0, tspan, opts, integrator=gu)
+    sr = ocs.fb_sweep_batch(reg, x0, tspan, opts, integrator=gr)
+    assert ocs.fb_sweep_path(gu) == (2 if batch % 64 == 0 else 1)
+    assert np.array_equal(su["sweeps"], sr["sweeps"]) and np.all(su["sweeps"] > 0)
+    for k, tol in (("J", 1e-11), ("x", 1e-10), ("lam", 1e-10), ("u", 1e-10)):
+        assert relerr(su[k], sr[k]) < tol, k
+    po = oracle.LogisticProblem(m, c, r, BOUNDS)
+    for b in sorted({0, batch // 2, batch - 1}):
+        so = oracle.fb_sweep(po, x0[:, b], tspan, opts)
+        assert su["sweeps"][b] == so["_sweeps"] and abs(su["J"][b] - so["J"]) < 1e-10 * abs(so["J"])
+        assert relerr(su["lam"][:, :, b], so["lam"]) < 1e-10 and relerr(su["u"][:, :, b], so["u"]) < 1e-10
