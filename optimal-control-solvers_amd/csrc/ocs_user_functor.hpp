@@ -14,6 +14,12 @@
 //   __device__ void ocs_ControlChar(double t, const double* x, const double* lam, OCS_PARAMS p,
 //                                   const double* lb, const double* ub, double* u);
 //
+//   (optional: #define OCS_USER_TCOEF in the source and give
+//   __device__ double ocs_tcoef(double t, OCS_PARAMS p);
+//    -- the three methods then receive ocs_tcoef(t, p) in the place of t, evaluated once per grid point into the integrator's
+//    step records instead of once per call: return exp(-r t) for a discounted objective whose dynamics do not read the time,
+//    which is what keeps the transcendental off the per-stage path (the registry problems hoist tests/TestOCProblem.m:25,31,37
+//    the same way).  The parameters it reads must be the same for all trajectories.)
 //   (optional: #define OCS_USER_CC_TCOEF in the source and give
 //   __device__ double ocs_cc_tcoef(double t, OCS_PARAMS p);
 //    -- ocs_ControlChar then receives ocs_cc_tcoef(t, p) in the place of t, evaluated once per grid point into the
@@ -115,8 +121,10 @@ struct UserP {
 #endif
 
   __device__ static inline void tcoef(double t, const double* ps, double* tc, double* tu) {
-#ifdef OCS_USER_ROWSEP
+#if defined(OCS_USER_ROWSEP)
     tc[0] = ocs_row_tcoef(t, (OCS_PARAMS)ps);   // the user's time coefficient (shared parameters)
+#elif defined(OCS_USER_TCOEF)
+    tc[0] = ocs_tcoef(t, (OCS_PARAMS)ps);       // ... of a problem given as full-vector methods
 #else
     (void)ps;
     tc[0] = t;

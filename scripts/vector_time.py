@@ -3,12 +3,13 @@ row-separable registry problem with the same shapes, per mapping.  BATCHES=4096 
 import os, sys, numpy as np, torch
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'))
 import __graft_entry__ as g
-from tests.user_problems import PREDPREY_PARAMS, PREDPREY_SRC
+from tests.user_problems import PREDPREY_PARAMS, PREDPREY_SRC, PREDPREY_TC_SRC
 ocs = g.load_package()
 dev = torch.device('cuda:0')
 N = int(os.environ.get('NSTEPS', '1000'))
 tspan = np.linspace(0, 6, N + 1)
 probs = {"predator-prey (user, coupled)": ocs.UserProblem(PREDPREY_SRC, 2, 1, PREDPREY_PARAMS, [[0.0, 1.0]]),
+         "predator-prey (user, coupled, ocs_tcoef)": ocs.UserProblem(PREDPREY_TC_SRC, 2, 1, PREDPREY_PARAMS, [[0.0, 1.0]]),
          "Logistic2 (registry, row-separable)": ocs.LogisticProblem([3.0, 2.5], 1.5, 0.05, [[0.0, 1.0]])}
 for batch in [int(b) for b in os.environ.get('BATCHES', '512,4096,16384').split(',')]:
     x0 = 1.0 + torch.rand((2, batch), dtype=torch.float64, device=dev)

@@ -189,6 +189,21 @@ def test_coupled_problem_outside_the_registry(ocs, oracle):
     assert relerr(dJdv, cs) < 1e-11
     with pytest.raises(ocs.OcsError):
         ocs.fb_sweep_batch(pu, x0[:, :1], tspan)  # no ocs_ControlChar in this plugin
+    # the same problem with its discount factor hoisted into the step records (OCS_USER_TCOEF: the methods receive
+    # ocs_tcoef(t, p) = e^{-rt} in the place of t): plugin evaluation, both passes on the lane kernels and on the vector mappings
+    from tests.user_problems import PREDPREY_TC_SRC
+    pt = ocs.UserProblem(PREDPREY_TC_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS)
+    tt, yy = rng.uniform(0, 6, 9), rng.uniform(0.5, 2.5, (3, 9))
+    ue, ve = rng.uniform(0, 1, (1, 9)), rng.normal(size=(3, 9))
+    assert relerr(pt.F(tt, yy, ue), pn.F(tt, yy, ue)) < 1e-14
+    assert relerr(pt.dFdx_times_vec(tt, yy, ue, ve), pn.dFdx_times_vec(tt, yy, ue, ve)) < 1e-14
+    assert relerr(pt.dFdu_times_vec(tt, yy, ue, ve), pn.dFdu_times_vec(tt, yy, ue, ve)) < 1e-14
+    for nb, mapping in ((batch, "auto"), (64, "auto"), (64, "lane")):
+        gt = ocs.RK4Integrator(tspan).set_mapping(mapping)
+        xt, Jt = gt.compute_states(pt, x0[:, :nb], uu[:, :, :nb])
+        lamt, dt = gt.compute_adjoints(pt, uu[:, :, :nb])
+        assert relerr(xt, x[:, :, :nb]) < 1e-13 and relerr(Jt, J[:nb]) < 1e-13
+        assert relerr(lamt, lam[:, :, :nb]) < 1e-12 and relerr(dt, dJdu[:, :, :nb]) < 1e-12
 
 
 def test_lq_problem_bl5_style(ocs, oracle):

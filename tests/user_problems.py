@@ -138,6 +138,25 @@ __device__ void ocs_dFdu_times_vec(double t, const double* y, const double* u, O
   g[0] = -y[1] * v[1] + exp(-p[7] * t) * 2 * p[4] * u[0] * v[2];
 }
 """
+# ... the same problem with the discount factor hoisted into the integrator's tables (OCS_USER_TCOEF: the methods receive
+# ocs_tcoef(t, p) = e^{-rt} in the place of t; the dynamics do not read the time)
+PREDPREY_TC_SRC = r"""
+#define OCS_USER_TCOEF 1
+__device__ double ocs_tcoef(double t, OCS_PARAMS p) { return exp(-p[7] * t); }
+__device__ void ocs_F(double e, const double* y, const double* u, OCS_PARAMS p, double* f) {
+  f[0] = y[0] * (p[0] - p[1] * y[1]);
+  f[1] = y[1] * (p[2] * y[0] - p[3]) - u[0] * y[1];
+  const double d = y[0] - p[6];
+  f[2] = e * (p[4] * u[0] * u[0] + p[5] * d * d);
+}
+__device__ void ocs_dFdx_times_vec(double e, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  g[0] = (p[0] - p[1] * y[1]) * v[0] + p[2] * y[1] * v[1] + e * 2 * p[5] * (y[0] - p[6]) * v[2];
+  g[1] = -p[1] * y[0] * v[0] + (p[2] * y[0] - p[3] - u[0]) * v[1];
+}
+__device__ void ocs_dFdu_times_vec(double e, const double* y, const double* u, OCS_PARAMS p, const double* v, double* g) {
+  g[0] = -y[1] * v[1] + e * 2 * p[4] * u[0] * v[2];
+}
+"""
 PREDPREY_PARAMS = [1.0, 0.5, 0.3, 0.6, 2.0, 1.5, 1.8, 0.05]
 
 
