@@ -78,6 +78,18 @@ def test_user_problem_sources_compile_for_gfx950(ocs):
     ocs.UserProblem.check_source(LOGISTIC2_SRC, 2, 1, 4, has_control_char=True)
     ocs.UserProblem.check_source(PREDPREY_SRC, 2, 1, 8)
     ocs.UserProblem.check_source(lq_source(6, 2), 6, 2, 1 + 36 + 12 + 6 + 2)   # > 16 parameters: uniform block
+    # every other form of a plugin, each with the kernel templates it selects: row functions (state pass, scan adjoint, costate
+    # scan reading u), + ControlChar of the costate alone (two-kernel sweep) with the tabulated ControlChar coefficient,
+    # ControlChar that reads x, full-vector methods with the tabulated time coefficient (vector mappings, costate vscan)
+    from tests.user_problems import (LOGISTIC_ROWS_SRC, LOGISTIC_ROWS_CC_SRC, LOGISTIC_ROWS_CCT_SRC, PROPHARVEST_ROWS_CC_SRC,
+                                     PREDPREY_TC_SRC)
+    ocs.UserProblem.check_source(LOGISTIC_ROWS_SRC, 4, 1, 6, row_separable=True)
+    ocs.UserProblem.check_source(LOGISTIC_ROWS_CC_SRC, 1, 1, 3, has_control_char=True, row_separable=True, control_from_costate=True)
+    ocs.UserProblem.check_source(LOGISTIC_ROWS_CCT_SRC, 2, 1, 4, has_control_char=True, row_separable=True, control_from_costate=True)
+    ocs.UserProblem.check_source(PROPHARVEST_ROWS_CC_SRC, 2, 1, 4, has_control_char=True, row_separable=True)
+    ocs.UserProblem.check_source(PREDPREY_TC_SRC, 2, 1, 8)
+    with pytest.raises(ocs.OcsError):   # the declaration needs row functions and ocs_ControlChar
+        ocs.UserProblem(LOGISTIC2_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], [[0.0, 1.0]], has_control_char=True, control_from_costate=True)
     with pytest.raises(ocs.OcsError) as e:
         ocs.UserProblem.check_source("__device__ void ocs_F(double t) { syntax error }", 1, 1, 0)
     assert e.value.code == -1 and "error" in str(e.value)
