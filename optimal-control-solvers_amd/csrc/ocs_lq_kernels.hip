@@ -548,12 +548,25 @@ __device__ static inline LQ2Pending xmv(LQ2X& X, const double (&Fo)[4], const do
   X.post<EXTRA>(vo, e0, e1);
   // two products ahead of the barrier: the wave blocks on the second until the first has left the pipe
   // (~70 cycles), which is about when its LDS writes have landed; the other two cover the read latency
+#ifndef OCS_LQ_TWO_CHAINS
+  // One accumulation chain: a dependent v_mfma_f64_16x16x4_f64 issues as soon as its predecessor leaves the pipe, so two
+  // chains gain nothing and their final addition (4 v_add_f64 behind the last result) only lengthens the stage's tail:
+  // state pass 11.79 -> 11.44 ms, adjoint 20.13 -> 19.77 ms at BL-5.
+  (void)z;
+  d4 acc = mma(Fo[0], vo[0], init);
+  acc = mma(Fo[1], vo[1], acc);
+  const LQ2Pending r = X.sync<EXTRA>();
+  const long long t1 = LQ_T();
+  acc = mma(Fo[2], vo[2], acc);
+  acc = mma(Fo[3], vo[3], acc);
+#else
   d4 acc = mma(Fo[0], vo[0], init);
   d4 alt = mma(Fo[1], vo[1], z);
   const LQ2Pending r = X.sync<EXTRA>();
   const long long t1 = LQ_T();
   acc = mma(Fo[2], vo[2], acc);
   alt = mma(Fo[3], vo[3], alt);
+#endif
   mid();
 #ifdef OCS_LQ_STAMPS
   __builtin_amdgcn_sched_barrier(0);
@@ -565,11 +578,18 @@ __device__ static inline LQ2Pending xmv(LQ2X& X, const double (&Fo)[4], const do
   __builtin_amdgcn_sched_barrier(0);
 #endif
   const long long t3 = LQ_T();
+#ifndef OCS_LQ_TWO_CHAINS
+  acc = mma(Fx[0], vx[0], acc);
+  acc = mma(Fx[1], vx[1], acc);
+  acc = mma(Fx[2], vx[2], acc);
+  acc = mma(Fx[3], vx[3], acc);
+#else
   acc = mma(Fx[0], vx[0], acc);
   alt = mma(Fx[1], vx[1], alt);
   acc = mma(Fx[2], vx[2], acc);
   alt = mma(Fx[3], vx[3], alt);
   acc += alt;
+#endif
   f[0] = acc.x; f[1] = acc.y; f[2] = acc.z; f[3] = acc.w;
 #ifndef OCS_LQ_STAMPS
   // Issue order of this region (from the barrier to the next post): one matrix instruction, then a few of the
@@ -597,16 +617,14 @@ __device__ static inline LQ2Pending xmv(LQ2X& X, const double (&Fo)[4], const do
 // the same product when both halves are already known (no exchange)
 __device__ static inline void mv2(const double (&Fo)[4], const double (&Fx)[4], const double (&vo)[4],
                                   const double (&vx)[4], d4 init, double (&f)[4]) {
-  const d4 z = {0.0, 0.0, 0.0, 0.0};
   d4 acc = mma(Fo[0], vo[0], init);
-  d4 alt = mma(Fo[1], vo[1], z);
+  acc = mma(Fo[1], vo[1], acc);
   acc = mma(Fo[2], vo[2], acc);
-  alt = mma(Fo[3], vo[3], alt);
+  acc = mma(Fo[3], vo[3], acc);
   acc = mma(Fx[0], vx[0], acc);
-  alt = mma(Fx[1], vx[1], alt);
+  acc = mma(Fx[1], vx[1], acc);
   acc = mma(Fx[2], vx[2], acc);
-  alt = mma(Fx[3], vx[3], alt);
-  acc += alt;
+  acc = mma(Fx[3], vx[3], acc);
   f[0] = acc.x; f[1] = acc.y; f[2] = acc.z; f[3] = acc.w;
 }
 
@@ -1079,14 +1097,13 @@ struct LQ4X {
   }
 };
 
-// four k-steps of one row tile: two accumulation chains
+// four k-steps of one row tile
 __device__ static inline d4 mv4(const double (&Fr)[4], const double (&v)[4], d4 init) {
-  const d4 z = {0.0, 0.0, 0.0, 0.0};
   d4 acc = mma(Fr[0], v[0], init);
-  d4 alt = mma(Fr[1], v[1], z);
+  acc = mma(Fr[1], v[1], acc);
   acc = mma(Fr[2], v[2], acc);
-  alt = mma(Fr[3], v[3], alt);
-  return acc + alt;
+  acc = mma(Fr[3], v[3], acc);
+  return acc;
 }
 __device__ static inline void d4_to(const d4 v, double (&f)[4]) { f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w; }
 
