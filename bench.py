@@ -266,6 +266,18 @@ def _replayed_traffic(name, nloc):
     return None, None
 
 
+def _replayed_variant_traffic(key):
+    """HBM bytes per pass pair of a secondary BL-2 entry from profiles/bl2_variants_traffic_latest.json
+    (scripts/profile_variants.sh + summarize_variants.py; replayed, not collected by this run)."""
+    try:
+        tr = json.load(open(os.path.join(ROOT, "profiles", "bl2_variants_traffic_latest.json")))["entries"].get(key)
+        if tr:
+            return tr["hbm_bytes_per_pass_pair"], f"{tr['source']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; replayed)"
+    except Exception:
+        pass
+    return None, None
+
+
 def pair_time(ocs, dev, nS, batch, reps=20, seed=20260410):
     """ms per pass pair (compute_states + compute_adjoints, full output, automatic mapping) of the BL-2 problem family."""
     tspan, x0_h, u_h = make_inputs(batch, dev, seed)
@@ -339,11 +351,12 @@ def bl2_large_batch_metric(ocs, dev, batch=65536, reps=5):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     nbytes = 8.0 * (3 * (NS + 1) + 6 * NC) * batch * NSTEPS
+    tr = _replayed_variant_traffic(f"lane_{NS}_{batch}")
     return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "mapping": "lane",
             "ms_per_pass_pair": dt * 1e3,
             "roofline": {"bound": "hbm", "kernel": "k_forward + k_backward (lane per trajectory), pass pair",
                          "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None, "traffic_source": None}}
+                         "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "traffic": tr[0], "traffic_source": tr[1]}}
 
 
 def bl2_single_state_metric(ocs, dev, batch=4096, reps=50):
@@ -369,13 +382,14 @@ def bl2_single_state_metric(ocs, dev, batch=4096, reps=50):
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / reps
     nbytes = 8.0 * (3 * 2 + 6 * 1) * batch * NSTEPS
+    tr = _replayed_variant_traffic(f"auto_1_{batch}")
     return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "nS": 1,
             "ms_per_pass_pair": dt * 1e3,
             "roofline": {"bound": "hbm (at 64 workgroups on 256 CUs the passes are bound by their serial chains: a quarter "
                                   "of the chip is in use)",
                          "kernel": "k_forward_p2 + k_backward_scan, pass pair", "achieved": nbytes / dt / 1e9,
                          "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS,
-                         "traffic": None, "traffic_source": None},
+                         "traffic": tr[0], "traffic_source": tr[1]},
             "finite": bool(torch.isfinite(J).all().item())}
 
 
