@@ -21,6 +21,7 @@
 #include "ocs_device_common.hpp"
 #include "ocs_internal.hpp"
 #include "ocs_rk4_kernels.hpp"
+#include "ocs_scan_kernel.hpp"   // Buf: raw buffer accesses with scalar offsets
 #include <cstdlib>
 #ifdef OCS_LQ_STAMPS
 #include <cstdio>
@@ -685,16 +686,26 @@ __global__ __launch_bounds__(256) void k_lq2_forward(const LQArgs a) {
     yo[j] = ro < nS ? a.x0[(size_t)ro * B + b] : 0.0;
     yx[j] = rx < nS ? a.x0[(size_t)rx * B + b] : 0.0;
   }
-  double* xo = a.x + (size_t)(16 * w + g) * B + b;
-  if (OUT_X) {
+  // Outputs and control samples go through raw buffer descriptors rebuilt per step on the scalar unit (base of the
+  // column) with a per-lane byte offset fixed for the whole pass: 64-bit pointer arithmetic per access was ~36 vector
+  // instructions per step, on the pipe the matrix instructions need.
+  const unsigned B8 = (unsigned)(B * 8);
+  unsigned vrow[4];   // byte offset of row 16w + 4j + g of this lane's trajectory inside a column (dropped if padded)
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (16 * w + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = yo[j];
+  for (int j = 0; j < 4; ++j)
+    vrow[j] = (FULL || 16 * w + 4 * j + g < nS) ? (unsigned)(((size_t)(16 * w + 4 * j + g) * B + b) * 8) : kOffDrop;
+  const unsigned vcost = (w == 0 && g == 0) ? (unsigned)(((size_t)nS * B + b) * 8) : kOffDrop;
+  if (OUT_X) {
+    const Buf bx0 = Buf::make(a.x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bx0.st0(yo[j], vrow[j], 0);
   }
 
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
+  const unsigned us8 = (unsigned)(ustride * 8);
   const double* up = a.u + (size_t)(uact ? g : 0) * B + b;
+  const unsigned vu = (unsigned)(((size_t)(uact ? g : 0) * B + b) * 8);
   double uA = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? *up : 0.0);
   double uM = uA, uB = uA;
   if (!UCONST) {
@@ -704,7 +715,6 @@ __global__ __launch_bounds__(256) void k_lq2_forward(const LQArgs a) {
   d4 buA = P.bu_times(uA), buM = buA, buB = buA;
   double F1[4];
   mv2(P.Ao, P.Ax, yo, yx, buA, F1);  // stage 1 of step 0 (later steps: under the y exchange of the step before)
-  double* xc = a.x + (size_t)nS * B + b;  // cost row of x, written one exchange late by wave 0 (see below)
   auto nothing = []() {};
 
   // Per-step inputs (uniform record, two control samples) are requested TWO steps ahead into two slots that the
@@ -719,9 +729,9 @@ __global__ __launch_bounds__(256) void k_lq2_forward(const LQArgs a) {
     q.r = load_rec<1>(a.REC + (size_t)i * rec_stride(1));  // the table is padded past step N-1
     if (!UCONST) {
       const int ic = i < N ? i : N - 1;
-      const double* pu = up + (size_t)(2 * ic) * ustride;
-      q.uM = pu[ustride];
-      q.uB = pu[2 * ustride];
+      const Buf bu = Buf::make(a.u + (size_t)(2 * ic) * ustride);
+      q.uM = bu.ld(vu, us8);
+      q.uB = bu.ld(vu, 2 * us8);
     }
   };
   auto step = [&](int i, Slot& q) OCS_INLINE {
@@ -763,16 +773,11 @@ __global__ __launch_bounds__(256) void k_lq2_forward(const LQArgs a) {
       yc = __builtin_fma(cur.h6, sum_over_g(cs), yc);
     });
     if (OUT_X) {
-      if (w == 0 && g == 0) xc[(size_t)i * nAugB] = ctot;
-      xo += nAugB;
-      if (FULL) {  // nS == 32: no padded rows, the step stays one basic block
+      const Buf bx = Buf::make(a.x + (size_t)i * nAugB);   // column i: its cost row; column i + 1: the state rows
+      bx.st0(ctot, vcost, 0);
+      const unsigned col8 = (unsigned)(nAugB * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) xo[(size_t)(4 * j) * B] = yo[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (16 * w + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = yo[j];
-      }
+      for (int j = 0; j < 4; ++j) bx.st0(yo[j], vrow[j], col8);
     }
     uA = uB;
     buA = buB;
@@ -791,7 +796,7 @@ __global__ __launch_bounds__(256) void k_lq2_forward(const LQArgs a) {
     const LQ2Pending r = X.sync<true>();
     if (w == 0 && g == 0) {
       const double Jt = yc + r.c.x;
-      if (OUT_X) xc[(size_t)N * nAugB] = Jt;
+      if (OUT_X) a.x[(size_t)N * nAugB + (size_t)nS * B + b] = Jt;
       a.J[b] = a.Jadd ? a.Jadd[b] + Jt : Jt;  // J = x(end,end)   :55
     }
   }
@@ -850,27 +855,31 @@ __global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
     lx_[j] = (a.lamT && rx < nS) ? a.lamT[(size_t)rx * B + b] : 0.0;
   }
   lamc = a.lamT ? a.lamT[(size_t)nS * B + b] : 1.0;
-  double* lp = a.lam + (size_t)N * nAugB + (size_t)(16 * w + g) * B + b;
-  auto store_lam = [&]() OCS_INLINE {
+  // raw buffer descriptors per column (scalar unit) + per-lane byte offsets fixed for the pass: see k_lq2_forward
+  unsigned vown[4], vpar[4];   // rows 16w + 4j + g and 16(1-w) + 4j + g of this lane's trajectory (dropped if padded)
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int ro = 16 * w + 4 * j + g, rx = 16 * (1 - w) + 4 * j + g;
+    vown[j] = (FULL || ro < nS) ? (unsigned)(((size_t)ro * B + b) * 8) : kOffDrop;
+    vpar[j] = (FULL || rx < nS) ? (unsigned)(((size_t)rx * B + b) * 8) : kOffDrop;
+  }
+  const unsigned vlamc = (w == 0 && g == 0) ? (unsigned)(((size_t)nS * B + b) * 8) : kOffDrop;
+  auto store_lam = [&](int col) OCS_INLINE {
     if (!OUT_LAM) return;
-    if (FULL) {
+    const Buf bl = Buf::make(a.lam + (size_t)col * nAugB);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) lp[(size_t)(4 * j) * B] = lo_[j];
-    } else {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (16 * w + 4 * j + g < nS) lp[(size_t)(4 * j) * B] = lo_[j];
-    }
-    if (w == 0 && g == 0) lp[(size_t)nS * B] = lamc;
-    lp -= nAugB;
+    for (int j = 0; j < 4; ++j) bl.st0(lo_[j], vown[j], 0);
+    bl.st0(lamc, vlamc, 0);
   };
-  store_lam();
+  store_lam(N);
 
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
   const size_t uoff = (size_t)(uact ? g : 0) * B + b;
   const double* up = a.u + uoff;
   double* dq = a.dJdu + uoff;
+  const unsigned vu = (unsigned)(uoff * 8), us8 = (unsigned)(ustride * 8);
+  const unsigned vdq = (w == 0 && uact) ? vu : kOffDrop;
   double uB = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? up[(size_t)(2 * N) * ustride] : 0.0);
   double uA = uB, uM = uB;
   if (!UCONST) {
@@ -881,12 +890,11 @@ __global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
   double k1co[4] = {0.0, 0.0, 0.0, 0.0}, k1lc = 0.0;
 
   auto load_ck = [&](int i, double (&o)[4], double (&x)[4]) OCS_INLINE {
-    const double* c = a.xck + (size_t)i * nAugB + b;
+    const Buf bc = Buf::make(a.xck + (size_t)i * nAugB);   // (a dropped access returns 0: the padded rows)
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const int ro = 16 * w + 4 * j + g, rx = 16 * (1 - w) + 4 * j + g;
-      o[j] = FULL ? c[(size_t)ro * B] : ld_sel(c, (size_t)ro * B, ro < nS);
-      x[j] = FULL ? c[(size_t)rx * B] : ld_sel(c, (size_t)rx * B, rx < nS);
+      o[j] = bc.ld(vown[j], 0);
+      x[j] = bc.ld(vpar[j], 0);
     }
   };
   // Per-step inputs (uniform record, checkpoint y_i, two control samples) are requested two steps ahead into
@@ -901,8 +909,9 @@ __global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
     const int ic = i > 0 ? i : 0;
     load_ck(ic, q.yo, q.yx);
     if (!UCONST) {
-      q.uA = up[(size_t)(2 * ic) * ustride];
-      q.uM = up[(size_t)(2 * ic + 1) * ustride];
+      const Buf bu = Buf::make(a.u + (size_t)(2 * ic) * ustride);
+      q.uA = bu.ld(vu, 0);
+      q.uM = bu.ld(vu, us8);
     }
   };
   double yo[4], F[4];
@@ -991,10 +1000,11 @@ __global__ __launch_bounds__(256) void k_lq2_backward(const LQArgs a) {
     const LQ2Pending rl = X.sync<OUT_DJDU>();
     mv2(P.Ao, P.Ax, qn.yo, qn.yx, buAn, F);
     LQ2X::take(rl, lx_);
-    store_lam();
-    if (OUT_DJDU && w == 0 && uact) {
-      dq[(size_t)(2 * i + 2) * ustride] = (pn + rl.c.x) + 2.0 * cur.tcB[0] * Rall * uB * (k4l + k1lc);
-      dq[(size_t)(2 * i + 1) * ustride] = (pm + rm.c.x) + 2.0 * cur.tcM[0] * Rall * uM * (k2l + k3l);
+    store_lam(i);
+    if (OUT_DJDU) {
+      const Buf bd = Buf::make(a.dJdu + (size_t)(2 * i + 1) * ustride);
+      bd.st0((pn + rl.c.x) + 2.0 * cur.tcB[0] * Rall * uB * (k4l + k1lc), vdq, us8);
+      bd.st0((pm + rm.c.x) + 2.0 * cur.tcM[0] * Rall * uM * (k2l + k3l), vdq, 0);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {

@@ -114,6 +114,9 @@ struct Buf {
 #endif
     return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(r, voff, soff, OCS_SCAN_LD_AUX));
   }
+  __device__ inline void st0(double v, unsigned voff, unsigned soff) const {   // plain (cached) store
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_sc, v), r, voff, soff, 0);
+  }
   __device__ inline void st(double v, unsigned voff, unsigned soff) const {
 #ifndef OCS_SCAN_ST_AUX
 #define OCS_SCAN_ST_AUX 2   // nt: see the note on non-temporal stores at the top of the file
