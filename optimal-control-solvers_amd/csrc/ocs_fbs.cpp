@@ -413,9 +413,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     mc = f->maxchange.d();
   }
   int* status = sweeps;
-  HIP_TRY(hipMemsetAsync(f->usel.p, 0, sizeof(int) * B, s));
-  HIP_TRY(hipMemsetAsync(status, 0, sizeof(int) * B, s));
-  HIP_TRY(hipMemsetAsync(mc, 0xFF, sizeof(double) * (size_t)opt->nSWEEPS * B, s));  // all-ones = NaN
+  LAUNCH_TRY(launch_fbs_init(batch, opt->nSWEEPS, (int*)f->usel.p, status, mc, s));  // usel = 0, status = 0, maxChange = NaN
   const ProblemDesc pd = describe(p);
   const GridDesc gd = describe(g);
   const FbsTables tb = tabs(g);

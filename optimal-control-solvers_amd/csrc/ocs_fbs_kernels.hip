@@ -140,6 +140,22 @@ int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* 
   return hip_rc3(hipGetLastError());
 }
 
+// start of a solve: usel = 0, status = 0, maxChange = NaN (all-ones) in one launch instead of three memsets
+__global__ void k_fbs_init(int batch, long long nmc, int* __restrict__ usel, int* __restrict__ status,
+                           unsigned long long* __restrict__ mc) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < batch) {
+    usel[i] = 0;
+    status[i] = 0;
+  }
+  if (i < nmc) mc[i] = ~0ull;
+}
+int launch_fbs_init(int batch, int nsweeps, int* usel, int* status, double* maxChange, hipStream_t s) {
+  const long long nmc = (long long)nsweeps * batch;
+  k_fbs_init<<<dim3((unsigned)((nmc + 255) / 256)), dim3(256), 0, s>>>(batch, nmc, usel, status, (unsigned long long*)maxChange);
+  return hip_rc3(hipGetLastError());
+}
+
 int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
                        double* maxChange, int* nactive, hipStream_t s, int ldb, const int* gate) {

@@ -260,6 +260,7 @@ int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const i
                        double absTol, hipStream_t s, double relax = 1.0);
 int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
 int control_pts_parts(int nq);  // rows of the partial-maximum array `metric` [parts][B] that launch_control_pts fills
+int launch_fbs_init(int batch, int nsweeps, int* usel, int* status, double* maxChange, hipStream_t s);
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
                        double* maxChange, int* nactive, hipStream_t s, int ldb = 0, const int* gate = nullptr);
 
