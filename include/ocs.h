@@ -78,7 +78,9 @@ int ocs_problem_create(ocs_problem *out, int problem_id, int nS, int nC, const d
 /* An OCProblem whose three plugin methods (OCProblem/OCProblem.m:8-21) are given as device C++ source and
  * compiled at run time with hipRTC for gfx950; contract of the source: csrc/ocs_user_functor.hpp (functions
  * ocs_F, ocs_dFdx_times_vec, ocs_dFdu_times_vec and, if has_control_char, ocs_ControlChar for fb_sweep).
- * Runs on the lane-per-trajectory kernels.  has_control_char is a flag word: bit 0 (value 1) -- the source defines
+ * Runs on the lane-per-trajectory kernels; for nS <= 4, nC <= 2 also on the vector-lane state pass and the scan adjoint
+ * with dense step maps (any coupled F).  Optional hooks in the source (csrc/ocs_user_functor.hpp): ocs_tcoef / ocs_cc_tcoef
+ * (time coefficients tabulated once per grid point).  has_control_char is a flag word: bit 0 (value 1) -- the source defines
  * ocs_ControlChar; bit 1 (value 2) -- the problem is ROW-SEPARABLE and the source defines row functions (ocs_row_F,
  * ocs_row_q, ocs_row_dFdy, ocs_row_dFdu: row r of F reads y_r, u and t only, the integrand is a sum of per-row shares;
  * nC = 1, nS in {1, 2, 4}, at most 16 parameters) from which the three methods are derived: such a problem also runs on
