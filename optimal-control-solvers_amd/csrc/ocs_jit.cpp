@@ -7,6 +7,10 @@
 
 #include <dlfcn.h>
 
+#include <memory>
+#include <mutex>
+#include <unordered_map>
+
 #include "ocs_jit.hpp"
 #include <cstdlib>
 
@@ -149,32 +153,69 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
                             "ocs_fbs_device.hpp", "ocs_pipeline2_kernel.hpp", "ocs_scan_kernel.hpp",
                             "ocs_pipelinev_kernel.hpp", "ocs_vscan_kernel.hpp", "ocs_fold_kernel.hpp",
                             "ocs_costate_scan_kernel.hpp", "ocs_costate_vscan_kernel.hpp"};
-  hiprtcProgram prog = nullptr;
-  if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 11, hdr_src, hdr_name) != 0) {
-    log = "hiprtcCreateProgram failed";
-    return OCS_ERR_HIP;
-  }
   const std::vector<std::string> names = kernel_names(nS, nC, rowsep, fold);
-  for (const std::string& n : names)
-    if (!n.empty()) r->AddNameExpression(prog, n.c_str());
-  // The include directory of the ROCm installation explicitly: hipRTC normally serves <hip/hip_runtime.h> from a built-in
-  // copy, but not in every process environment (under rocprofv3 started from another directory the compilation failed
-  // with "'hip/hip_runtime.h' file not found").
-  const char* rocm = getenv("ROCM_PATH");
-  if (!rocm || !*rocm) rocm = getenv("HIP_PATH");
-  const std::string inc = std::string("-I") + ((rocm && *rocm) ? rocm : "/opt/rocm") + "/include";
-  const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc.c_str()};
-  const hiprtcResult rc = r->CompileProgram(prog, 5, opts);
-  size_t logsz = 0;
-  r->GetProgramLogSize(prog, &logsz);
-  if (logsz > 1) {
-    log.resize(logsz);
-    r->GetProgramLog(prog, &log[0]);
+  // Compiled code is kept for the life of the process, keyed by the full generated source (the kernel headers are fixed
+  // per build of the library): creating the same problem again -- parameter studies, a test suite -- costs a module load
+  // instead of 5-6 s of hipRTC.
+  struct Compiled {
+    std::vector<char> code;
+    std::vector<std::string> lowered;
+  };
+  static std::mutex cache_mu;
+  static std::unordered_map<std::string, std::shared_ptr<const Compiled>> cache;
+  std::shared_ptr<const Compiled> cc;
+  {
+    std::lock_guard<std::mutex> lk(cache_mu);
+    auto it = cache.find(src);
+    if (it != cache.end()) cc = it->second;
   }
-  if (rc != 0) {
+  if (!cc) {
+    hiprtcProgram prog = nullptr;
+    if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 11, hdr_src, hdr_name) != 0) {
+      log = "hiprtcCreateProgram failed";
+      return OCS_ERR_HIP;
+    }
+    for (const std::string& n : names)
+      if (!n.empty()) r->AddNameExpression(prog, n.c_str());
+    // The include directory of the ROCm installation explicitly: hipRTC normally serves <hip/hip_runtime.h> from a built-in
+    // copy, but not in every process environment (under rocprofv3 started from another directory the compilation failed
+    // with "'hip/hip_runtime.h' file not found").
+    const char* rocm = getenv("ROCM_PATH");
+    if (!rocm || !*rocm) rocm = getenv("HIP_PATH");
+    const std::string inc = std::string("-I") + ((rocm && *rocm) ? rocm : "/opt/rocm") + "/include";
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=fast", inc.c_str()};
+    const hiprtcResult rc = r->CompileProgram(prog, 5, opts);
+    size_t logsz = 0;
+    r->GetProgramLogSize(prog, &logsz);
+    if (logsz > 1) {
+      log.resize(logsz);
+      r->GetProgramLog(prog, &log[0]);
+    }
+    if (rc != 0) {
+      r->DestroyProgram(&prog);
+      if (log.empty()) log = "hiprtcCompileProgram failed";
+      return OCS_ERR_INVALID;
+    }
+    auto fresh = std::make_shared<Compiled>();
+    fresh->lowered.resize(UK_COUNT);
+    for (int k = 0; k < UK_COUNT; ++k) {
+      if (names[k].empty()) continue;
+      const char* ln = nullptr;
+      if (r->GetLoweredName(prog, names[k].c_str(), &ln) != 0 || !ln) {
+        r->DestroyProgram(&prog);
+        log = "no lowered name for " + names[k];
+        return OCS_ERR_HIP;
+      }
+      fresh->lowered[k] = ln;
+    }
+    size_t sz = 0;
+    r->GetCodeSize(prog, &sz);
+    fresh->code.resize(sz);
+    r->GetCode(prog, fresh->code.data());
     r->DestroyProgram(&prog);
-    if (log.empty()) log = "hiprtcCompileProgram failed";
-    return OCS_ERR_INVALID;
+    cc = fresh;
+    std::lock_guard<std::mutex> lk(cache_mu);
+    cache.emplace(src, cc);
   }
   UserModule* m = new UserModule();
   m->nS = nS;
@@ -185,23 +226,8 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   m->vector = vec;
   m->fold = fold;
   m->chunk = user_chunk(nS);
-  std::vector<std::string> lowered(UK_COUNT);
-  for (int k = 0; k < UK_COUNT; ++k) {
-    if (names[k].empty()) continue;
-    const char* ln = nullptr;
-    if (r->GetLoweredName(prog, names[k].c_str(), &ln) != 0 || !ln) {
-      r->DestroyProgram(&prog);
-      delete m;
-      log = "no lowered name for " + names[k];
-      return OCS_ERR_HIP;
-    }
-    lowered[k] = ln;
-  }
-  size_t sz = 0;
-  r->GetCodeSize(prog, &sz);
-  m->code.resize(sz);
-  r->GetCode(prog, m->code.data());
-  r->DestroyProgram(&prog);
+  m->code = cc->code;
+  const std::vector<std::string>& lowered = cc->lowered;
   if (load) {
     if (require_device() != OCS_OK) {
       delete m;
