@@ -5,8 +5,11 @@
 //   u = reshape(v,nC,[]) * B          (ChebyshevControl.m:35-38)   [B x nBasis] . [nBasis x (2N+1)]
 //   dJdv = dJdu * B'                  (ChebyshevControl.m:41-43)   [B x (2N+1)] . [(2N+1) x nBasis]
 //
-// are genuine matrix products over the batch; on v_mfma_f64_16x16x4_f64 they run beside the vector pipe instead of
-// taking 32 + 32 + 32 of its ~170 fp64 instructions per (trajectory, step).  Neither u nor dJdu exists in memory: HBM
+// are genuine matrix products over the batch: as tiles of v_mfma_f64_16x16x4_f64 they take one issue slot per 1024
+// multiply-adds and keep their operands in registers, instead of 32 + 32 + 32 of the ~170 fp64 vector instructions per
+// (trajectory, step).  (They do not take less PIPE time: on gfx950 the fp64 matrix instruction occupies the SIMD's fp64
+// datapath for its 64 cycles -- scripts/probe/mfma_valu_overlap.hip -- which is why this path is the choice of the
+// latency-bound small batches and the lane kernels that of the full chip.)  Neither u nor dJdu exists in memory: HBM
 // traffic per (trajectory, step) is the checkpoint write + read of the state rows, 16 nS bytes.
 //
 //   state pass    k_forward_p2<..., NKS> (ocs_pipeline2_kernel.hpp): expansion waves U produce the block of samples the
