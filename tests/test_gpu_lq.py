@@ -203,3 +203,51 @@ def test_bl5_full_size_properties(ocs):
     assert bool((lam[:, nS, :] == 1.0).all())
     # padding trajectories repeat the first ones bit for bit (lane-placement independence)
     assert bool((x[:, :, 3 * third:] == x[:, :, :pad]).all()) and bool((dJdu[:, :, 3 * third:] == dJdu[:, :, :pad]).all())
+
+
+@pytest.mark.parametrize("mapping", [0, 1, 2, 3])
+@pytest.mark.parametrize("nS", [7, 32])
+def test_known_answer_decoupled_linear_system(ocs, mapping, nS):
+    """A known answer that owes nothing to the oracle: for x' = diag(lambda) x + Bu u with constant u and q = 0 the RK4
+    recursion (RK4Integrator.m:37-51) has the closed form x_{i+1} = R(h lambda) x_i + h phi(h lambda) Bu u with the
+    stability polynomial R(z) = 1 + z + z^2/2 + z^3/6 + z^4/24 and phi(z) = 1 + z/2 + z^2/6 + z^3/24; with the objective
+    integrand e^{-rt} u'Ru alone the discrete adjoint (:72-88) is lam_i = R(h lambda) lam_{i+1} and dJ/du at the nodes follows
+    from the quadrature weights.  Checked in extended precision (numpy longdouble) on every LQ mapping."""
+    rng = np.random.default_rng(nS)
+    nC, N, batch, T, r = 2, 48, 37, 1.2, 0.05
+    lam_k = -rng.uniform(0.2, 6.0, nS)
+    A = np.diag(lam_k)
+    Bu = rng.normal(size=(nS, nC))
+    q, rd = np.zeros(nS), rng.uniform(0.5, 2.0, nC)
+    pg = ocs.LQProblem(A, Bu, q, rd, r, [[-1.0, 1.0]] * nC)
+    tspan = np.linspace(0.0, T, N + 1)
+    g = ocs.RK4Integrator(tspan).set_mapping(mapping)
+    uc = rng.uniform(-1, 1, (nC, batch))
+    u = np.repeat(uc[:, None, :], 2 * N + 1, axis=1)
+    x0 = rng.normal(size=(nS, batch))
+    lamT = np.vstack([rng.normal(size=(nS, batch)), np.ones((1, batch))])
+    x, J = g.compute_states(pg, x0, u)
+    lam, dJdu = g.compute_adjoints(pg, u, lamT)
+    L = np.longdouble
+    h = np.diff(tspan.astype(L))
+    xr = x0.astype(L).copy()
+    Bu_u = Bu.astype(L) @ uc.astype(L)
+    for i in range(N):
+        z = (h[i] * lam_k.astype(L))[:, None]
+        R = 1 + z + z**2 / 2 + z**3 / 6 + z**4 / 24
+        phi = 1 + z / 2 + z**2 / 6 + z**3 / 24
+        xr = R * xr + h[i] * phi * Bu_u
+    assert relerr(x[:nS, -1, :], xr.astype(np.float64)) < 1e-13
+    # objective: the integrand does not depend on x: J = sum_i h_i/6 (e_A + 4 e_M + e_B) u'Ru
+    tg = g.t.astype(L)
+    e = np.exp(-L(r) * tg)
+    w = np.sum(h / 6 * (e[0:-1:2] + 4 * e[1::2] + e[2::2]))
+    Jr = w * np.sum(rd.astype(L)[:, None] * uc.astype(L) ** 2, axis=0)
+    assert relerr(J, Jr.astype(np.float64)) < 1e-13
+    # adjoint: lam(1:nS, 0) = prod_i R(h_i lambda) lamT(1:nS)   (q = 0: no coupling to the cost row)
+    lr = lamT[:nS].astype(L).copy()
+    for i in range(N - 1, -1, -1):
+        z = (h[i] * lam_k.astype(L))[:, None]
+        lr = (1 + z + z**2 / 2 + z**3 / 6 + z**4 / 24) * lr
+    assert relerr(lam[:nS, 0, :], lr.astype(np.float64)) < 1e-13 and np.all(lam[nS] == 1.0)
+    assert np.all(np.isfinite(dJdu)) and dJdu.shape == u.shape

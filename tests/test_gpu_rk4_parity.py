@@ -383,3 +383,39 @@ def test_single_state_pipeline_adjoint(ocs, oracle, N, batch, T):
     for b in (0, batch - 1):
         go.compute_states(po, x0[:, b], u[:, :, b])
         assert relerr(lam2[:, :, b], go.compute_adjoints(po, u[:, :, b], lamT[:, b], want_dJdu=False)) < RTOL
+
+
+@pytest.mark.parametrize("mapping", ["auto", "lane", "rowsplit"])
+def test_known_answers_without_the_oracle(ocs, mapping):
+    """Known answers that owe nothing to the oracle, on the GPU kernels themselves (TestOCProblem.m:22-38 generalised to nS
+    rows): (1) with u = 0 the state equation x' = x (m - x) has the closed form m x0 e^{mt} / (m + x0 (e^{mt} - 1)); the
+    kernels' RK4 (RK4Integrator.m:37-51) must approach it at fourth order under grid refinement; (2) at the constant control
+    u* and state x* = (m + sqrt(m^2 - 4 u*)) / 2 -- an equilibrium of the row -- the state stays put and
+    J = c u*^2 ... + x*^2 summed against the quadrature of e^{-rt}: sum_i h/6 (e_A + 4 e_M + e_B) (sum_r x*_r^2 + c u*^2)."""
+    m = [3.0, 2.5, 2.0, 1.5]
+    c, r, T, batch = 1.5, 0.05, 2.0, 64
+    prob = ocs.LogisticProblem(m, c, r, BOUNDS)
+    rng = np.random.default_rng(11)
+    x0 = rng.uniform(0.2, 2.0, (4, batch))
+    errs = []
+    for N in (64, 128):
+        tspan = np.linspace(0.0, T, N + 1)
+        g = ocs.RK4Integrator(tspan).set_mapping(mapping)
+        x, _ = g.compute_states(prob, x0, np.zeros((1, 2 * N + 1, batch)))
+        mm = np.asarray(m)[:, None]
+        exact = mm * x0 * np.exp(mm * T) / (mm + x0 * (np.exp(mm * T) - 1.0))
+        errs.append(np.max(np.abs(x[:4, -1, :] - exact)))
+    assert errs[0] < 2e-6 and 12.0 < errs[0] / errs[1] < 20.0   # fourth order: halving h divides the error by ~16
+    # (2) equilibrium of every row under a constant control
+    ustar, N = 0.4, 96
+    xs = np.array([(mk + np.sqrt(mk * mk - 4 * ustar)) / 2 for mk in m])
+    tspan = np.linspace(0.0, T, N + 1)
+    g = ocs.RK4Integrator(tspan).set_mapping(mapping)
+    x, J = g.compute_states(prob, np.repeat(xs[:, None], batch, axis=1), np.full((1, 2 * N + 1, batch), ustar))
+    assert np.max(np.abs(x[:4] - xs[:, None, None])) < 1e-13
+    L = np.longdouble
+    h = np.diff(tspan.astype(L))
+    e = np.exp(-L(r) * g.t.astype(L))
+    w = np.sum(h / 6 * (e[0:-1:2] + 4 * e[1::2] + e[2::2]))
+    Jr = float(w * (np.sum(xs.astype(L) ** 2) + L(c) * L(ustar) ** 2))
+    assert np.max(np.abs(J - Jr)) < 1e-12 * Jr
