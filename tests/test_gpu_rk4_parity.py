@@ -419,3 +419,46 @@ def test_known_answers_without_the_oracle(ocs, mapping):
     w = np.sum(h / 6 * (e[0:-1:2] + 4 * e[1::2] + e[2::2]))
     Jr = float(w * (np.sum(xs.astype(L) ** 2) + L(c) * L(ustar) ** 2))
     assert np.max(np.abs(J - Jr)) < 1e-12 * Jr
+
+
+@pytest.mark.parametrize("kind,mapping", [("logistic4", "auto"), ("logistic4", "lane"), ("logistic3", "auto"), ("logistic1", "auto"),
+                                          ("lq32", 2), ("lq32", 3), ("lq20", 1), ("predprey", "auto"), ("predprey", "lane")])
+def test_adjoint_is_the_gradient_of_the_state_pass_without_the_oracle(ocs, kind, mapping):
+    """The adjoint kernels against the state kernels alone (no oracle): dJdu of compute_adjoints (RK4Integrator.m:59-121) is
+    the exact gradient of the discrete J of compute_states (:28-56), so its product with a direction d equals the
+    directional derivative of J, taken here by a fourth-order central difference
+    (8 (J(u + e d) - J(u - e d)) - (J(u + 2 e d) - J(u - 2 e d))) / (12 e) -- the four shifted controls of every trajectory
+    ride in the batch.  Agreement to < 5e-9 relative pins every adjoint mapping to its state pass."""
+    rng = np.random.default_rng(sum(map(ord, kind)))
+    N, nb, eps = 64, 64, 1e-3
+    if kind.startswith("logistic"):
+        nS, nC, T = int(kind[-1]), 1, 2.0
+        prob = ocs.LogisticProblem([3.0, 2.5, 2.0, 1.5][:nS], 1.5, 0.05, BOUNDS)
+        x0 = rng.uniform(0.8, 1.6, (nS, nb))
+        u = rng.uniform(0.1, 0.4, (nC, 2 * N + 1, nb))
+    elif kind.startswith("lq"):
+        from tests.user_problems import lq_matrices
+        nS, nC, T = int(kind[2:]), 3, 0.4
+        A, Bu, q, rd = lq_matrices(nS, nC)
+        prob = ocs.LQProblem(A, Bu, q, rd, 0.05, [[-1.0, 1.0]] * nC)
+        x0 = rng.normal(size=(nS, nb))
+        u = rng.uniform(-1, 1, (nC, 2 * N + 1, nb))
+    else:
+        from tests.user_problems import PREDPREY_PARAMS, PREDPREY_SRC
+        nS, nC, T = 2, 1, 3.0
+        prob = ocs.UserProblem(PREDPREY_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS)
+        x0 = rng.uniform(1.0, 2.5, (nS, nb))
+        u = rng.uniform(0.0, 1.0, (nC, 2 * N + 1, nb))
+    d = rng.normal(size=u.shape)
+    g = ocs.RK4Integrator(np.linspace(0.0, T, N + 1)).set_mapping(mapping)
+    _, J0 = g.compute_states(prob, x0, u)
+    _, dJdu = g.compute_adjoints(prob, u)
+    shifts = (1.0, -1.0, 2.0, -2.0)
+    ub = np.concatenate([u + s * eps * d for s in shifts], axis=2)     # four shifted copies of the batch
+    _, Jb = g.compute_states(prob, np.tile(x0, (1, 4)), ub)
+    Jp, Jm, Jpp, Jmm = (Jb[k * nb:(k + 1) * nb] for k in range(4))
+    fd = (8.0 * (Jp - Jm) - (Jpp - Jmm)) / (12.0 * eps)
+    an = np.sum(dJdu * d, axis=(0, 1))
+    scale = np.maximum(np.abs(an), np.abs(J0) * 1e-3 + 1e-6)
+    print(kind, mapping, "max relative difference", float(np.max(np.abs(an - fd) / scale)))
+    assert np.max(np.abs(an - fd) / scale) < 5e-9   # (observed 2e-11 .. 4e-10: truncation of the difference formula)
