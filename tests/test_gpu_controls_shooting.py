@@ -483,3 +483,36 @@ def test_fused_banded_control_objective_gradient(ocs, oracle, kind, nS, nB, N, b
         Jo, do, x0o = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b], FreeInitStates=free)
         assert abs(Jf[b] - Jo) < RTOL * max(1.0, abs(Jo)) and relerr(df[:, b], do) < RTOL
     cg.set_fusion("auto")
+
+
+@pytest.mark.parametrize("basis,nB,mode,batch", [("cheb", 16, "on", 64), ("cheb", 16, "lane", 64), ("cheb", 11, "lane", 70),
+                                                 ("cheb", 16, "off", 64), ("pwl", 21, "auto", 64), ("pwc", 10, "auto", 64)])
+def test_shooting_gradient_is_the_gradient_of_the_objective_without_the_oracle(ocs, basis, nB, mode, batch):
+    """single_shooting.m:137-150 held against itself on the GPU (no oracle): dJdv of nlpObjective is the exact gradient of
+    its J, so dJdv . d equals the directional derivative of J along d, taken by a fourth-order central difference whose four
+    shifted coefficient vectors ride in the batch.  Every fusion mode of the Chebyshev basis (wave-specialised + scan with
+    the products on the matrix cores, lane kernels in one wave / two roles, unfused), piecewise-linear and
+    piecewise-constant bases; free initial states included."""
+    rng = np.random.default_rng(nB * 7 + batch)
+    N, eps, T = 64, 1e-3, 4.0
+    g = ocs.RK4Integrator(np.linspace(0.0, T, N + 1))
+    ctrl = {"cheb": ocs.ChebyshevControl, "pwl": ocs.PWLinearControl, "pwc": ocs.PWConstantControl}[basis](g.t, nB, 1)
+    if basis == "cheb":
+        ctrl.set_fusion(mode)
+    prob = ocs.LogisticProblem([3.0], P["c"], P["r"], BOUNDS)
+    nV = ctrl.nBasis + 1                                  # + one free initial state
+    v = np.vstack([0.3 + 0.05 * rng.normal(size=(ctrl.nBasis, batch)) / (1 + np.arange(ctrl.nBasis))[:, None] ** (basis == "cheb"),
+                   rng.uniform(0.9, 1.4, (1, batch))])
+    x0 = rng.uniform(0.9, 1.4, (1, batch))
+    d = rng.normal(size=(nV, batch))
+    J0, dJdv, _ = ocs.nlp_objective(g, prob, ctrl, x0.copy(), v, FreeInitStates=[1])
+    vb = np.concatenate([v + s * eps * d for s in (1.0, -1.0, 2.0, -2.0)], axis=1)
+    Jb, _, _ = ocs.nlp_objective(g, prob, ctrl, np.tile(x0, (1, 4)), vb, FreeInitStates=[1])
+    Jp, Jm, Jpp, Jmm = (Jb[k * batch:(k + 1) * batch] for k in range(4))
+    fd = (8.0 * (Jp - Jm) - (Jpp - Jmm)) / (12.0 * eps)
+    an = np.sum(dJdv * d, axis=0)
+    scale = np.maximum(np.abs(an), np.abs(J0) * 1e-3 + 1e-6)
+    print(basis, nB, mode, "max relative difference", float(np.max(np.abs(an - fd) / scale)))
+    assert np.max(np.abs(an - fd) / scale) < 5e-9
+    if basis == "cheb":
+        ctrl.set_fusion("auto")

@@ -390,3 +390,21 @@ def test_fold_stress_per_instance(ocs, oracle):
         assert r["ok"], (case, r["failures"][:4])
         assert r["sweeps"].max() >= want[case] and (r["sweeps"] == 0).any(), (case, r["sweeps"].max())
         assert r["err_fold"] < 1e-11 and r["err_oracle"] < 1e-10
+
+
+def test_device_pchip_against_scipy(ocs):
+    """vectorInterpolant.m:6 ('pchip') on the device against scipy's PchipInterpolator (Fritsch-Carlson with MATLAB's end
+    slopes): no oracle involved.  Non-uniform nodes, monotone and oscillating data, query points on nodes and between."""
+    import torch
+    from scipy.interpolate import PchipInterpolator
+    rng = np.random.default_rng(5)
+    n, batch = 41, 7
+    x = np.concatenate([[0.0], np.sort(rng.uniform(0, 3, n - 2)), [3.0]])
+    v = np.stack([np.cumsum(rng.uniform(0, 1, (n, batch)), axis=0), np.sin(3 * x)[:, None] * rng.normal(size=(1, batch))])   # [2][n][batch]
+    q = np.concatenate([x[::5], rng.uniform(0, 3, 50)])
+    vd = torch.tensor(np.ascontiguousarray(v.transpose(1, 0, 2)), device="cuda")   # [n][comp][batch]
+    got = ocs.vectorInterpolant_dev(x, vd, "pchip")(q).cpu().numpy()               # [nq][comp][batch]
+    for c in range(2):
+        for b in range(batch):
+            ref = PchipInterpolator(x, v[c, :, b])(q)
+            assert np.max(np.abs(got[:, c, b] - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref)))
