@@ -408,3 +408,41 @@ def test_device_pchip_against_scipy(ocs):
         for b in range(batch):
             ref = PchipInterpolator(x, v[c, :, b])(q)
             assert np.max(np.abs(got[:, c, b] - ref)) < 1e-13 * max(1.0, np.max(np.abs(ref)))
+
+
+@pytest.mark.parametrize("nS,batch", [(1, 128), (2, 64), (4, 32)])
+def test_fb_sweep_solution_properties_without_the_oracle(ocs, nS, batch):
+    """Properties of soln = fb_sweep(...) that need no oracle (fb_sweep.m:79-125): the returned control is ControlChar of
+    the returned costate at the interpolation points (:123; here = the grid nodes, numpy restatement of
+    TestOCProblem's ControlChar), the recorded change of the control is <= 1 exactly in the sweep an instance converged
+    in and > 1 in every sweep before (:108-110), lam(TF) = 0 (compute_x_lam.m:4), and the control the solution
+    implies reproduces the solution's state and costate through compute_x_lam to the order of the sweep's tolerance."""
+    c, r, N, T = 1.5, 0.05, 200, 8.0
+    m = [3.0, 2.5, 2.0, 3.5][:nS]
+    rng = np.random.default_rng(nS)
+    x0 = rng.uniform(0.8, 1.6, (nS, batch))
+    tspan = ocs.linspace(0, T, N + 1)
+    prob = ocs.LogisticProblem(m, c, r, [[0.0, 1.0]])
+    g = ocs.RK4Integrator(tspan)
+    s = ocs.fb_sweep_batch(prob, x0, tspan, {"nERROR_PTS": N + 1, "nINTERP_PTS": N + 1}, integrator=g)
+    ok = s["sweeps"] > 0
+    assert ok.mean() > 0.75   # (with four states a few instances do not converge in 20 sweeps)
+    t = np.asarray(tspan)
+    u_cc = np.clip(np.sum(s["lam"], axis=0) * np.exp(r * t)[:, None] / (2 * c), 0.0, 1.0)       # [N+1][batch]
+    assert np.max(np.abs(s["u"][0][:, ok] - u_cc[:, ok])) < 1e-13
+    assert np.all(s["lam"][:, -1, :][:, ok] == 0.0)
+    mc = s["maxChange"]
+    for b in np.flatnonzero(ok)[:16]:
+        k = s["sweeps"][b]
+        assert mc[k - 1, b] <= 1.0 and np.all(mc[:k - 1, b] > 1.0) and np.all(np.isnan(mc[k:, b]))
+    # the control the solution implies, on the 2N+1 grid (midpoints: ControlChar of the pchip midpoints of lam), through
+    # compute_x_lam: x and lam come back to within the sweep's tolerance (uRelTol = 1e-3 on the control)
+    from scipy.interpolate import PchipInterpolator
+    tg = np.asarray(g.t)
+    bsel = [int(i) for i in np.flatnonzero(ok)[:4]]
+    ug = np.empty((1, 2 * N + 1, len(bsel)))
+    for j, b in enumerate(bsel):
+        lam_g = np.stack([PchipInterpolator(t, s["lam"][k, :, b])(tg) for k in range(nS)])
+        ug[0, :, j] = np.clip(lam_g.sum(axis=0) * np.exp(r * tg) / (2 * c), 0.0, 1.0)
+    x2, lam2 = ocs.compute_x_lam(prob, x0[:, bsel], tspan, ug, integrator=ocs.RK4Integrator(tspan))
+    assert np.max(np.abs(x2 - s["x"][:, :, bsel])) < 2e-2 and np.max(np.abs(lam2 - s["lam"][:, :, bsel])) < 2e-2
