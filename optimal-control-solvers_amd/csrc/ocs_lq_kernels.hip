@@ -206,26 +206,25 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
 #pragma unroll
   for (int m = 0; m < KS; ++m) y[m] = (4 * m + g < nS) ? a.x0[(size_t)(4 * m + g) * B + b] : 0.0;
 
-  double* xo = a.x + (size_t)g * B + b;
-  const bool full = nS == 16 * RT;
-  auto store_x = [&]() OCS_INLINE {
+  // (global accesses through raw buffer descriptors built per column on the scalar unit, per-lane byte offsets fixed for
+  //  the pass: no 64-bit vector address arithmetic on the pipe the matrix instructions need -- see k_lq2_forward)
+  unsigned vrow[KS];
+#pragma unroll
+  for (int m = 0; m < KS; ++m) vrow[m] = (4 * m + g < nS) ? (unsigned)(((size_t)(4 * m + g) * B + b) * 8) : kOffDrop;
+  const unsigned vcost = (g == 0) ? (unsigned)(((size_t)nS * B + b) * 8) : kOffDrop;
+  auto store_x = [&](int col) OCS_INLINE {
     if (!OUT_X) return;
-    if (full) {
+    const Buf bx = Buf::make(a.x + (size_t)col * nAugB);
 #pragma unroll
-      for (int m = 0; m < KS; ++m) xo[(size_t)(4 * m) * B] = y[m];
-    } else {
-#pragma unroll
-      for (int m = 0; m < KS; ++m)
-        if (4 * m + g < nS) xo[(size_t)(4 * m) * B] = y[m];
-    }
-    if (g == 0) xo[(size_t)nS * B] = yc;
-    xo += nAugB;
+    for (int m = 0; m < KS; ++m) bx.st0(y[m], vrow[m], 0);
+    bx.st0(yc, vcost, 0);
   };
-  store_x();
+  store_x(0);
 
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
   const double* up = a.u + (size_t)(uact ? g : 0) * B + b;  // u(:,1) of this lane's control row
+  const unsigned vu = (unsigned)(((size_t)(uact ? g : 0) * B + b) * 8), us8 = (unsigned)(ustride * 8);
   double uA = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? *up : 0.0);
   d4 buA[RT], buM[RT], buB[RT];
   P.bu_times(uA, buA);
@@ -248,8 +247,8 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
     double uMn = uM, uBn = uB;
     if (!UCONST) {
       const int in = i + 1 < N ? i + 1 : i;
-      const double* q = up + (size_t)(2 * in) * ustride;
-      const double vM = q[ustride], vB = q[2 * ustride];  // unused control rows read row 0 and are zeroed
+      const Buf bu = Buf::make(a.u + (size_t)(2 * in) * ustride);
+      const double vM = bu.ld(vu, us8), vB = bu.ld(vu, 2 * us8);  // unused control rows read row 0 and are zeroed
       uMn = uact ? vM : 0.0;
       uBn = uact ? vB : 0.0;
       P.bu_times(uM, buM);
@@ -274,7 +273,7 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
     for (int m = 0; m < KS; ++m)                                              // :50
       y[m] = __builtin_fma(cur.h6, (F1[m] + 2.0 * F2[m]) + (2.0 * F3[m] + F4[m]), y[m]);
     yc = __builtin_fma(cur.h6, sum_over_g(cs), yc);
-    store_x();
+    store_x(i + 1);
     cur = nxt;
     uA = uB;
     uM = uMn;
@@ -338,28 +337,25 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
   for (int m = 0; m < KS; ++m) lam[m] = (a.lamT && 4 * m + g < nS) ? a.lamT[(size_t)(4 * m + g) * B + b] : 0.0;
   lamc = a.lamT ? a.lamT[(size_t)nS * B + b] : 1.0;
 
-  double* lo = a.lam + (size_t)N * nAugB + (size_t)g * B + b;
-  const bool full = nS == 16 * RT;
-  auto store_lam = [&]() OCS_INLINE {
+  unsigned vrow[KS];   // (raw buffer descriptors per column: see k_lq_forward)
+#pragma unroll
+  for (int m = 0; m < KS; ++m) vrow[m] = (4 * m + g < nS) ? (unsigned)(((size_t)(4 * m + g) * B + b) * 8) : kOffDrop;
+  const unsigned vlamc = (g == 0) ? (unsigned)(((size_t)nS * B + b) * 8) : kOffDrop;
+  auto store_lam = [&](int col) OCS_INLINE {
     if (!OUT_LAM) return;
-    if (full) {
+    const Buf bl = Buf::make(a.lam + (size_t)col * nAugB);
 #pragma unroll
-      for (int m = 0; m < KS; ++m) lo[(size_t)(4 * m) * B] = lam[m];
-    } else {
-#pragma unroll
-      for (int m = 0; m < KS; ++m)
-        if (4 * m + g < nS) lo[(size_t)(4 * m) * B] = lam[m];
-    }
-    if (g == 0) lo[(size_t)nS * B] = lamc;
-    lo -= nAugB;
+    for (int m = 0; m < KS; ++m) bl.st0(lam[m], vrow[m], 0);
+    bl.st0(lamc, vlamc, 0);
   };
-  store_lam();
+  store_lam(N);
 
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
   const size_t uoff = (size_t)(uact ? g : 0) * B + b;
   const double* up = a.u + uoff;
   double* dq = a.dJdu + uoff;
+  const unsigned vu = (unsigned)(uoff * 8), us8 = (unsigned)(ustride * 8), vdq = uact ? vu : kOffDrop;
   double uB = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? up[(size_t)(2 * N) * ustride] : 0.0);
   double uA = uB, uM = uB;
   d4 buA[RT], buM[RT];
@@ -388,13 +384,14 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
     recp -= rec_stride(1);
     const Rec nxt = load_rec<1>(recp);  // the table is padded before step 0
     const int ip = i > 0 ? i - 1 : 0;
-    const double* cq = a.xck + (size_t)ip * nAugB + b;
+    const Buf bc = Buf::make(a.xck + (size_t)ip * nAugB);   // (a dropped access returns 0: the padded rows)
     double yn[KS];
 #pragma unroll
-    for (int m = 0; m < KS; ++m) yn[m] = ld_sel(cq, (size_t)(4 * m + g) * B, 4 * m + g < nS);
+    for (int m = 0; m < KS; ++m) yn[m] = bc.ld(vrow[m], 0);
     double uAn = uA, uMn = uM;
     if (!UCONST) {
-      const double vA = up[(size_t)(2 * ip) * ustride], vM = up[(size_t)(2 * ip + 1) * ustride];
+      const Buf bu = Buf::make(a.u + (size_t)(2 * ip) * ustride);
+      const double vA = bu.ld(vu, 0), vM = bu.ld(vu, us8);
       uAn = uact ? vA : 0.0;
       uMn = uact ? vM : 0.0;
       P.bu_times(uA, buA);
@@ -437,17 +434,16 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
 #pragma unroll
       for (int m = 0; m < KS; ++m) v[m] = k2[m] + k3[m];
       const double dm = but_times(v) + 2.0 * cur.tcM[0] * P.R * uM * (k2l + k3l);
-      if (uact) {
-        dq[(size_t)(2 * i + 2) * ustride] = dn;
-        dq[(size_t)(2 * i + 1) * ustride] = dm;
-      }
+      const Buf bd = Buf::make(a.dJdu + (size_t)(2 * i + 1) * ustride);
+      bd.st0(dn, vdq, us8);
+      bd.st0(dm, vdq, 0);
 #pragma unroll
       for (int m = 0; m < KS; ++m) k1c[m] = k1[m];
       k1lc = k1l;
     }
 #pragma unroll
     for (int m = 0; m < KS; ++m) lam[m] = (((lam[m] + g1[m]) + g2[m]) + g3[m]) + g0[m];  // :86-88
-    store_lam();
+    store_lam(i);
 
     eA0 = cur.tcA[0];
     cur = nxt;
