@@ -123,15 +123,6 @@ __device__ static inline void unpack(const d4 (&acc)[RT], double (&f)[4 * RT]) {
   }
 }
 
-// Guarded accesses without divergent branches: a padded row / an unused control row reads a valid
-// address and the value is replaced by 0; stores take a uniform fast path when nothing is padded.
-// (exec-masked branches around every access would split the step into many basic blocks: the waitcnt
-// pass then cannot count the loads in flight and the matrix products get moved across the exchanges.)
-__device__ static inline double ld_sel(const double* base, size_t off, bool ok) {
-  const double v = base[ok ? off : 0];
-  return ok ? v : 0.0;
-}
-
 // sum over the four lanes (g = 0..3) that share a trajectory
 __device__ static inline double sum_over_g(double v) {
   v += __shfl_xor(v, 16);
@@ -1158,16 +1149,22 @@ __global__ __launch_bounds__(256) void k_lq4_forward(const LQArgs a) {
     const int r = 16 * h + 4 * j + g;
     y[j] = r < nS ? a.x0[(size_t)r * B + b] : 0.0;
   }
-  double* xo = a.x + (size_t)(16 * h + g) * B + b;
   const bool storew = w == 1;   // the waves (1, h) store the rows of tile h
-  if (OUT_X && storew) {
+  // (raw buffer descriptors per column, per-lane byte offsets fixed for the pass: see k_lq2_forward)
+  unsigned vrow[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      if (16 * h + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = y[j];
+  for (int j = 0; j < 4; ++j)
+    vrow[j] = (storew && (FULL || 16 * h + 4 * j + g < nS)) ? (unsigned)(((size_t)(16 * h + 4 * j + g) * B + b) * 8) : kOffDrop;
+  const unsigned vcost = (wv == 0 && g == 0) ? (unsigned)(((size_t)nS * B + b) * 8) : kOffDrop;
+  if (OUT_X) {
+    const Buf bx0 = Buf::make(a.x);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bx0.st0(y[j], vrow[j], 0);
   }
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
   const double* up = a.u + (size_t)(uact ? g : 0) * B + b;
+  const unsigned vu = (unsigned)(((size_t)(uact ? g : 0) * B + b) * 8), us8 = (unsigned)(ustride * 8);
   double uA = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? *up : 0.0);
   double uM = uA, uB = uA;
   d4 buA = bu_times(uA), buM = buA, buB = buA;
@@ -1179,8 +1176,6 @@ __global__ __launch_bounds__(256) void k_lq4_forward(const LQArgs a) {
     X.fetch<1, false>(S, e0, e1);
     d4_to(S[0], F1);
   }
-  double* xc = a.x + (size_t)nS * B + b;
-
   struct Slot {
     Rec r;
     double uM, uB;
@@ -1189,9 +1184,9 @@ __global__ __launch_bounds__(256) void k_lq4_forward(const LQArgs a) {
     s.r = load_rec<1>(a.REC + (size_t)i * rec_stride(1));  // the table is padded past step N-1
     if (!UCONST) {
       const int ic = i < N ? i : N - 1;
-      const double* pu = up + (size_t)(2 * ic) * ustride;
-      s.uM = pu[ustride];
-      s.uB = pu[2 * ustride];
+      const Buf bu = Buf::make(a.u + (size_t)(2 * ic) * ustride);
+      s.uM = bu.ld(vu, us8);
+      s.uB = bu.ld(vu, 2 * us8);
     }
   };
   auto step = [&](int i, Slot& sl) OCS_INLINE {
@@ -1237,18 +1232,11 @@ __global__ __launch_bounds__(256) void k_lq4_forward(const LQArgs a) {
     X.post<1, false>(P);
     if (costw) yc = __builtin_fma(cur.h6, sum_over_g(cs), yc);
     if (OUT_X) {
-      if (wv == 0 && g == 0) xc[(size_t)i * nAugB] = ctot;
-      if (storew) {
-        xo += nAugB;
-        if (FULL) {
+      const Buf bx = Buf::make(a.x + (size_t)i * nAugB);   // column i: its cost row; column i + 1: the state rows
+      bx.st0(ctot, vcost, 0);
+      const unsigned col8 = (unsigned)(nAugB * 8);
 #pragma unroll
-          for (int j = 0; j < 4; ++j) xo[(size_t)(4 * j) * B] = y[j];
-        } else {
-#pragma unroll
-          for (int j = 0; j < 4; ++j)
-            if (16 * h + 4 * j + g < nS) xo[(size_t)(4 * j) * B] = y[j];
-        }
-      }
+      for (int j = 0; j < 4; ++j) bx.st0(y[j], vrow[j], col8);
     }
     X.fetch<1, false>(S, e0, e1);
     d4_to(S[0], F1);
@@ -1270,7 +1258,7 @@ __global__ __launch_bounds__(256) void k_lq4_forward(const LQArgs a) {
     X.fetch<1, true>(S, e0, e1);
     if (wv == 0 && g == 0) {
       const double Jt = e0.x + e1.x;
-      if (OUT_X) xc[(size_t)N * nAugB] = Jt;
+      if (OUT_X) a.x[(size_t)N * nAugB + (size_t)nS * B + b] = Jt;
       a.J[b] = a.Jadd ? a.Jadd[b] + Jt : Jt;  // J = x(end,end)   :55
     }
   }
@@ -1331,29 +1319,28 @@ __global__ __launch_bounds__(256) void k_lq4_backward(const LQArgs a) {
   }
   lamc = a.lamT ? a.lamT[(size_t)nS * B + b] : 1.0;
   const bool storew = w == 1;   // the waves (1, h) store lam of tile h
-  double* lp = a.lam + (size_t)N * nAugB + (size_t)(16 * h + g) * B + b;
-  auto store_lam = [&]() OCS_INLINE {
+  unsigned vrow[4], vst[4];   // rows of tile h of this lane's trajectory: loads (every wave), stores (waves (1, h))
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    vrow[j] = (FULL || 16 * h + 4 * j + g < nS) ? (unsigned)(((size_t)(16 * h + 4 * j + g) * B + b) * 8) : kOffDrop;
+    vst[j] = storew ? vrow[j] : kOffDrop;
+  }
+  const unsigned vlamc = (wv == 2 && g == 0) ? (unsigned)(((size_t)nS * B + b) * 8) : kOffDrop;
+  auto store_lam = [&](int col) OCS_INLINE {
     if (!OUT_LAM) return;
-    if (storew) {
-      if (FULL) {
+    const Buf bl = Buf::make(a.lam + (size_t)col * nAugB);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) lp[(size_t)(4 * j) * B] = lam[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (16 * h + 4 * j + g < nS) lp[(size_t)(4 * j) * B] = lam[j];
-      }
-      if (wv == 2 && g == 0) lp[(size_t)nS * B] = lamc;   // (wave (1, 0), g = 0: lp points at row 0)
-    }
-    lp -= nAugB;
+    for (int j = 0; j < 4; ++j) bl.st0(lam[j], vst[j], 0);
+    bl.st0(lamc, vlamc, 0);
   };
-  store_lam();
+  store_lam(N);
 
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
   const size_t uoff = (size_t)(uact ? g : 0) * B + b;
   const double* up = a.u + uoff;
   double* dq = a.dJdu + uoff;
+  const unsigned vu = (unsigned)(uoff * 8), us8 = (unsigned)(ustride * 8);
   double uB = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? up[(size_t)(2 * N) * ustride] : 0.0);
   double uA = uB, uM = uB;
   if (!UCONST) {
@@ -1364,12 +1351,9 @@ __global__ __launch_bounds__(256) void k_lq4_backward(const LQArgs a) {
   double k1c[4] = {0.0, 0.0, 0.0, 0.0}, k1lc = 0.0;
 
   auto load_ck = [&](int i, double (&o)[4]) OCS_INLINE {
-    const double* c = a.xck + (size_t)i * nAugB + b;
+    const Buf bc = Buf::make(a.xck + (size_t)i * nAugB);   // (a dropped access returns 0: the padded rows)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int r = 16 * h + 4 * j + g;
-      o[j] = FULL ? c[(size_t)r * B] : ld_sel(c, (size_t)r * B, r < nS);
-    }
+    for (int j = 0; j < 4; ++j) o[j] = bc.ld(vrow[j], 0);
   };
   struct Slot {
     Rec r;
@@ -1381,8 +1365,9 @@ __global__ __launch_bounds__(256) void k_lq4_backward(const LQArgs a) {
     const int ic = i > 0 ? i : 0;
     load_ck(ic, s.y);
     if (!UCONST) {
-      s.uA = up[(size_t)(2 * ic) * ustride];
-      s.uM = up[(size_t)(2 * ic + 1) * ustride];
+      const Buf bu = Buf::make(a.u + (size_t)(2 * ic) * ustride);
+      s.uA = bu.ld(vu, 0);
+      s.uM = bu.ld(vu, us8);
     }
   };
   double yo[4], F[4];
@@ -1459,11 +1444,12 @@ __global__ __launch_bounds__(256) void k_lq4_backward(const LQArgs a) {
     d4_to(S2[1], F);
 #pragma unroll
     for (int j = 0; j < 4; ++j) lam[j] = (((lam[j] + g1[j]) + g2[j]) + g3[j]) + g0[j];
-    store_lam();
-    if (OUT_DJDU && uact) {
+    store_lam(i);
+    if (OUT_DJDU) {
       // wave 0 = (0, 0) has read the midpoint parts of the waves (0, 0), (0, 1); wave 3 = (1, 1) the node parts of (1, 0), (1, 1)
-      if (wv == 3) dq[(size_t)(2 * i + 2) * ustride] = (e0.x + e1.x) + 2.0 * cur.tcB[0] * Rall * uB * (k4l + k1lc);
-      if (wv == 0) dq[(size_t)(2 * i + 1) * ustride] = (e0.x + e1.x) + 2.0 * cur.tcM[0] * Rall * uM * (k2l + k3l);
+      const Buf bd = Buf::make(a.dJdu + (size_t)(2 * i + 1) * ustride);
+      bd.st0((e0.x + e1.x) + 2.0 * cur.tcB[0] * Rall * uB * (k4l + k1lc), (wv == 3 && uact) ? vu : kOffDrop, us8);
+      bd.st0((e0.x + e1.x) + 2.0 * cur.tcM[0] * Rall * uM * (k2l + k3l), (wv == 0 && uact) ? vu : kOffDrop, 0);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
