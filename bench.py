@@ -110,13 +110,16 @@ def _sync():
     torch.cuda.synchronize()
 
 
-def fb_sweep_metric(ocs, dev, batch=16384, reps=5, shard=True):
+def fb_sweep_metric(ocs, dev, batch=16384, reps=20, shard=True, prewarm_s=0.3):
     """Second half of BASELINE.json's metric: fb_sweep iters/sec on configs[2] (SURVEY BL-3):
     TestOCProblem through the A9 adapter, T=10, N=1000 forward + 1000 backward, batch=16384 instances with
     x0 ~ U(0.5,2.5), c ~ U(1,2) (seed 20260402), u0 = lower bound, default tolerances, <= 50 sweeps.
     One iter = forward + costate + control update + convergence reduction for one instance; converged
     instances stop counting (the whole batch still runs until the last one is done).  Under world > 1 the instances
-    shard into contiguous blocks (no exchange; the count of iterations is all-reduced)."""
+    shard into contiguous blocks (no exchange; the count of iterations is all-reduced).
+    Timing: >= prewarm_s seconds of untimed solves (the leg's own work, like the headline's pre-warm), then `reps`
+    solves timed one by one (sync on both sides of each); `value` follows the MEDIAN, and min / max / the per-rep
+    list are in the line.  The output tensors are allocated once and written by every solve (`out=`)."""
     world, rank, lo, hi = _shard(ocs, batch) if shard else (1, 0, 0, batch)
     rng = np.random.default_rng(20260402)
     tspan = ocs.linspace(0.0, T_END, NSTEPS + 1)  # MATLAB's linspace, as fb_sweep.m:69-70 builds its point sets
@@ -125,13 +128,13 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=5, shard=True):
     prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
     prob.set_batch_params([0], cs[None, :])
     integ = ocs.RK4Integrator(tspan)
-    for _ in range(3):  # warm-up (allocations, tables, clocks: the legs before this one end with host work)
-        ocs.fb_sweep_dev(prob, integ, x0)
-    res = {}
+    res = {"r": ocs.fb_sweep_dev(prob, integ, x0)}   # first call: allocations, tables
 
     def solve():
-        res["r"] = ocs.fb_sweep_dev(prob, integ, x0)
-    dt = ocs.distributed.timed_max_over_ranks(solve, reps, _sync)
+        res["r"] = ocs.fb_sweep_dev(prob, integ, x0, out=res["r"])
+    n_warm = ocs.distributed.prewarm(solve, prewarm_s, _sync)
+    per_rep = ocs.distributed.timed_reps_max_over_ranks(solve, reps, _sync)
+    sp, dt = ocs.distributed.spread(per_rep)
     sw = res["r"]["sweeps"].cpu().numpy()
     tot = torch.tensor([float(np.where(sw > 0, sw, 50).sum()), float((sw > 0).sum()), float(sw.max())],
                        dtype=torch.float64, device=dev)
@@ -162,10 +165,13 @@ def fb_sweep_metric(ocs, dev, batch=16384, reps=5, shard=True):
     except Exception:
         fb_traffic = None
     return {"value": iters / dt, "unit": "fb_sweep iters/s (instance-sweeps)", "batch": batch, "n_steps": NSTEPS,
-            "batch_per_gpu": hi - lo, "seconds_per_solve": dt,
+            "batch_per_gpu": hi - lo, "seconds_per_solve": dt, "ms_per_solve": sp,
+            "timing": f"median of {reps} solves timed one by one after {n_warm} untimed solves (>= {prewarm_s} s); "
+                      "outputs allocated once",
             "sweeps_min": int(sw[sw > 0].min()) if (sw > 0).any() else 0,
             "sweeps_max": int(smax), "fraction_converged": nconv / batch,
             "batch_sweeps_per_s": bsps,
+            "sweep_loop": ocs.fb_sweep_path(integ),
             "roofline": {"bound": "hbm", "kernel": "one sweep of the local batch: state pass with the control update "
                                                    "folded in (k_forward_cc) + costate pass with the convergence test "
                                                    "(k_costate_plx, MET)",
@@ -185,7 +191,7 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 peak, vector = matrix (public spec); the
                           # (scripts/probe/mfma_valu_overlap.hip), so this is the fp64 roofline whatever the mix
 
 
-def bl4_metric(ocs, dev, batch=65536, reps=5, shard=True):
+def bl4_metric(ocs, dev, batch=65536, reps=12, shard=True):
     """BASELINE configs[3] (SURVEY BL-4): single_shooting objective + gradient (single_shooting.m:137-150) with a
     Chebyshev basis of 16 coefficients, TestOCProblem, N = 1000, batch = 65536 coefficient vectors (seed 20260403),
     sharded into contiguous blocks (8192 per GPU at 8 GPUs) through distributed.sharded_objective_eval: one evaluation
@@ -222,18 +228,19 @@ def bl4_metric(ocs, dev, batch=65536, reps=5, shard=True):
 
     def one():
         out["r"] = ocs.distributed.sharded_objective_eval(eval_local, Vg) if shard else None
-    for _ in range(3):
-        eval_local(Vl)
-        one()
-    # `value`: the evaluations themselves (the data path), barrier-bracketed, max over ranks; the KB-size
-    # post-reductions (J all-gather, best candidate, ensemble mean; each ends in a host read) are timed with them
-    # once more and reported beside it
-    dt = ocs.distributed.timed_max_over_ranks(lambda: eval_local(Vl), reps, _sync)
+    eval_local(Vl)
+    one()
+    # `value`: the evaluations themselves (the data path), max over ranks; >= 0.3 s of untimed evaluations first, then
+    # `reps` groups of 5 evaluations timed one group at a time (median); the KB-size post-reductions (J all-gather, best
+    # candidate, ensemble mean; each ends in a host read) are timed with them once more and reported beside it
+    ocs.distributed.prewarm(lambda: eval_local(Vl), 0.3, _sync, chunk=10)
+    sp, dt = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(lambda: eval_local(Vl), reps, _sync, inner=5))
     res = {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s inside objective+gradient evaluations",
            "batch": batch, "batch_per_gpu": nloc, "n_basis": 16, "ms_per_batch_evaluation": dt * 1e3,
+           "ms_per_batch_evaluation_spread": sp,
            "evaluations_per_s": batch / dt, "finite": bool(torch.isfinite(G).all().item())}
     if shard:
-        dt_red = ocs.distributed.timed_max_over_ranks(one, reps, _sync)
+        dt_red = ocs.distributed.timed_max_over_ranks(one, 5, _sync)
         r = out["r"]
         res.update({"ms_per_evaluation_with_post_reductions": dt_red * 1e3,
                     "best_candidate": {"J": r["best"][0], "index": r["best"][1]}, "J_all_gathered": int(r["J_all"].numel())})
@@ -278,27 +285,79 @@ def _replayed_variant_traffic(key):
     return None, None
 
 
-def pair_time(ocs, dev, nS, batch, reps=20, seed=20260410):
-    """ms per pass pair (compute_states + compute_adjoints, full output, automatic mapping) of the BL-2 problem family."""
+def _pair_buffers(ocs, dev, nS, batch, seed, nsets=1):
     tspan, x0_h, u_h = make_inputs(batch, dev, seed)
+    x0 = torch.tensor(np.ascontiguousarray(x0_h[:nS]), device=dev)
+    sets = []
+    for k in range(nsets):
+        u = torch.tensor(u_h, device=dev) if k == 0 else sets[0][0].clone()
+        x = torch.empty((NSTEPS + 1, nS + 1, batch), dtype=torch.float64, device=dev)
+        sets.append((u, x, torch.empty_like(x), torch.empty_like(u)))
+    J = torch.empty(batch, dtype=torch.float64, device=dev)
+    return tspan, x0, sets, J
+
+
+def pair_time(ocs, dev, nS, batch, reps=12, seed=20260410, spread=False):
+    """ms per pass pair (compute_states + compute_adjoints, full output, automatic mapping) of the BL-2 problem family:
+    >= 0.2 s of untimed pairs, then `reps` groups of 10 pairs (5 above batch 8192) timed group by group; the median."""
+    tspan, x0, sets, J = _pair_buffers(ocs, dev, nS, batch, seed)
+    u, x, lam, dJdu = sets[0]
     prob = ocs.LogisticProblem(M[:nS], C_PAR, R_PAR, [[0.0, 1.0]])
     integ = ocs.RK4Integrator(tspan)
-    x0, u = torch.tensor(np.ascontiguousarray(x0_h[:nS]), device=dev), torch.tensor(u_h, device=dev)
-    x = torch.empty((NSTEPS + 1, nS + 1, batch), dtype=torch.float64, device=dev)
-    lam, dJdu = torch.empty_like(x), torch.empty_like(u)
-    J = torch.empty(batch, dtype=torch.float64, device=dev)
 
     def pair():
         integ.compute_states_dev(prob, x0, u, x, J)
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
-    for _ in range(10):
-        pair()
+    ocs.distributed.prewarm(pair, 0.2, _sync, chunk=10)
+    sp, med = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(pair, reps, _sync, inner=10 if batch <= 8192 else 5))
+    return (med * 1e3, sp) if spread else med * 1e3
+
+
+def bl2_rotated_metric(ocs, dev, batch=BATCH, nsets=3, reps=20):
+    """The BL-2 pass pair with NO reuse of a buffer from one step to the next: `nsets` complete buffer sets (u, x, lam,
+    dJdu: 458 MB each at batch 4096, so three of them are 5.4 x the 256 MiB Infinity Cache) are used round-robin, one set
+    per step; a set is touched again only after all the others.  The headline loop re-uses ONE set, whose u (65 MB) and x
+    (164 MB) can stay in the memory-side cache between steps -- this entry is the figure with every byte coming from and
+    going to HBM.  Same kernels, same roofline arithmetic; per-kernel times from HIP events on the launch stream in
+    a separate untimed loop."""
+    nS = NS
+    tspan, x0, sets, J = _pair_buffers(ocs, dev, nS, batch, 20260401, nsets)
+    prob = ocs.LogisticProblem(M, C_PAR, R_PAR, [[0.0, 1.0]])
+    integ = ocs.RK4Integrator(tspan)
+    state = {"k": 0}
+
+    def step():
+        u, x, lam, dJdu = sets[state["k"] % nsets]
+        state["k"] += 1
+        integ.compute_states_dev(prob, x0, u, x, J)
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+    ocs.distributed.prewarm(step, 0.4, _sync, chunk=nsets * 5)
+    nev = 30
+    ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nev)]
+    for k in range(nev):
+        u, x, lam, dJdu = sets[k % nsets]
+        ev[k][0].record()
+        integ.compute_states_dev(prob, x0, u, x, J)
+        ev[k][1].record()
+        integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
+        ev[k][2].record()
     torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pair()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / reps * 1e3
+    t_f = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
+    t_b = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    state["k"] = 0
+    sp, dt = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(step, reps, _sync, inner=nsets * 4))
+    nA = nS + 1
+    b_f, b_b = 8 * (nA + 2 * NC) * batch * NSTEPS, 8 * (2 * nA + 4 * NC) * batch * NSTEPS
+    return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "buffer_sets": nsets,
+            "bytes_per_buffer_set": int(sum(t.numel() * 8 for t in sets[0])), "ms_per_pass_pair": dt * 1e3,
+            "ms_per_pass_pair_spread": sp,
+            "roofline": {"bound": "hbm", "kernel": "k_forward_p2 + k_backward_scan, pass pair, rotating buffer sets",
+                         "achieved": (b_f + b_b) / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (b_f + b_b) / dt / 1e9 / HBM_PEAK_GBPS, "traffic": None,
+                         "algorithmic_bytes_per_pass_pair": b_f + b_b},
+            "kernels": {"k_forward": {"median_s": t_f, "GBps": b_f / t_f / 1e9},
+                        "k_backward": {"median_s": t_b, "GBps": b_b / t_b / 1e9, "frac": b_b / t_b / 1e9 / HBM_PEAK_GBPS}},
+            "finite": bool(torch.isfinite(J).all().item())}
 
 
 def strong_scaling_readiness(ocs, dev):
@@ -309,7 +368,7 @@ def strong_scaling_readiness(ocs, dev):
     out = {"definition": "predicted_efficiency_8gpu = t(B) / (8 * t(B/8)), both measured on one GPU; the data path has no collective"}
     sweep = {}
     for b in (512, 1024, 2048, 4096, 8192, 16384, 32768, 65536):
-        sweep[str(b)] = pair_time(ocs, dev, NS, b, reps=20 if b <= 8192 else 8)
+        sweep[str(b)] = pair_time(ocs, dev, NS, b, reps=12 if b <= 8192 else 6)
     out["BL-2 pass pair ms by batch (LogisticK nS=4, N=1000, automatic mapping)"] = sweep
     out["BL-2"] = {"B": 4096, "ms_B": sweep["4096"], "ms_shard": sweep["512"],
                    "predicted_efficiency_8gpu": sweep["4096"] / (8 * sweep["512"])}
@@ -329,7 +388,7 @@ def strong_scaling_readiness(ocs, dev):
     return out
 
 
-def bl2_large_batch_metric(ocs, dev, batch=65536, reps=5):
+def bl2_large_batch_metric(ocs, dev, batch=65536, reps=8):
     """The BL-2 problem in the HBM-bound regime (the lane-per-trajectory mapping at batch 65 536, full output): the
     figure DESIGN.md quotes for "what the passes reach once the chip is full"."""
     tspan, x0_h, u_h = make_inputs(batch, dev, 20260409)
@@ -343,23 +402,18 @@ def bl2_large_batch_metric(ocs, dev, batch=65536, reps=5):
     def pair():
         integ.compute_states_dev(prob, x0, u, x, J)
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
-    pair()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pair()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    ocs.distributed.prewarm(pair, 0.2, _sync, chunk=5)
+    sp, dt = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(pair, reps, _sync, inner=3))
     nbytes = 8.0 * (3 * (NS + 1) + 6 * NC) * batch * NSTEPS
     tr = _replayed_variant_traffic(f"lane_{NS}_{batch}")
     return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "mapping": "lane",
-            "ms_per_pass_pair": dt * 1e3,
+            "ms_per_pass_pair": dt * 1e3, "ms_per_pass_pair_spread": sp,
             "roofline": {"bound": "hbm", "kernel": "k_forward + k_backward (lane per trajectory), pass pair",
                          "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "traffic": tr[0], "traffic_source": tr[1]}}
 
 
-def bl2_single_state_metric(ocs, dev, batch=4096, reps=50):
+def bl2_single_state_metric(ocs, dev, batch=4096, reps=12):
     """"reduces to TestOCProblem when nS = 1 -- also benchmark that nAug = 2 case": the same grid,
     batch and candidates with one state (96 B per trajectory-step), automatic mapping (k_forward_p2 + k_backward_scan)."""
     tspan, _, u_h = make_inputs(batch, dev, 20260401)
@@ -373,18 +427,12 @@ def bl2_single_state_metric(ocs, dev, batch=4096, reps=50):
     def pair():
         integ.compute_states_dev(prob, x0, u, x, J)
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
-    for _ in range(20):
-        pair()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(reps):
-        pair()
-    torch.cuda.synchronize()
-    dt = (time.perf_counter() - t0) / reps
+    ocs.distributed.prewarm(pair, 0.2, _sync, chunk=10)
+    sp, dt = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(pair, reps, _sync, inner=10))
     nbytes = 8.0 * (3 * 2 + 6 * 1) * batch * NSTEPS
     tr = _replayed_variant_traffic(f"auto_1_{batch}")
     return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "nS": 1,
-            "ms_per_pass_pair": dt * 1e3,
+            "ms_per_pass_pair": dt * 1e3, "ms_per_pass_pair_spread": sp,
             "roofline": {"bound": "hbm (at 64 workgroups on 256 CUs the passes are bound by their serial chains: a quarter "
                                   "of the chip is in use)",
                          "kernel": "k_forward_p2 + k_backward_scan, pass pair", "achieved": nbytes / dt / 1e9,
@@ -437,7 +485,7 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2, shard=True):
     def pair():
         integ.compute_states_dev(prob, x0, u, x, J)
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
-    dt = ocs.distributed.timed_max_over_ranks(pair, reps, _sync)      # whole job: barrier, max over ranks
+    sp5, dt = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(pair, max(reps, 3), _sync))  # whole job: max over ranks, median
     steps_local = nloc * 2 * N                # RK4 steps of both legs (main + tail) on this rank
     # algorithmic flops per (trajectory, step): 4 F + 3 recomputed F + 4 A'k products of 2 nS^2, the Bu u / Bu' k
     # products, O(nS) axpys not counted (12 mat-vecs, here 11 because F4 is not needed in the adjoint)
@@ -454,7 +502,7 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2, shard=True):
         pass
     return {"value": batch * 2 * N / dt, "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
             "batch": batch, "batch_per_gpu": nloc, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3,
-            "ms_adjoint": tb * 1e3, "ms_pass_pair_max_over_ranks": dt * 1e3,
+            "ms_adjoint": tb * 1e3, "ms_pass_pair_max_over_ranks": dt * 1e3, "ms_pass_pair_spread": sp5,
             "roofline": {"bound": "mfma", "kernel": ("k_lq4_backward (adjoint + dJdu, both legs; four waves per 16 trajectories, "
                                                      "products split over K), this rank" if nloc <= 4096 else
                                                      "k_lq2_backward (adjoint + dJdu, both legs; two waves per 16 "
@@ -580,6 +628,8 @@ def main():
     # per-kernel durations from HIP events on the launch stream (torch's current stream)
     t_fwd = float(np.mean([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     t_bwd = float(np.mean([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
+    ev_f = sorted(e[0].elapsed_time(e[1]) * 1e3 for e in ev)
+    ev_b = sorted(e[1].elapsed_time(e[2]) * 1e3 for e in ev)
     nA = NS + 1
     bytes_fwd = 8 * (nA + 2 * NC) * batch * NSTEPS           # write x, read u (2 new samples/step)
     bytes_bwd = 8 * (2 * nA + 4 * NC) * batch * NSTEPS       # read x, write lam, read u, write dJdu
@@ -633,6 +683,8 @@ def main():
                                       "bound": "dependent chain of the state recursion (8 fp64 operations per step)"},
                         "k_backward": {"avg_s": t_bwd, "alg_bytes": bytes_bwd,
                                        "GBps": bytes_bwd / t_bwd / 1e9},
+                        "event_us_min_median_max": {"k_forward": [round(ev_f[0], 2), round(ev_f[len(ev_f) // 2], 2), round(ev_f[-1], 2)],
+                                                    "k_backward": [round(ev_b[0], 2), round(ev_b[len(ev_b) // 2], 2), round(ev_b[-1], 2)]},
                         # the pass pair over the timed (event-free) steps of this rank
                         "pass_pair_GBps": (bytes_fwd + bytes_bwd) * args.steps / dt / 1e9,
                         "pass_pair_frac": (bytes_fwd + bytes_bwd) * args.steps / dt / 1e9 / HBM_PEAK_GBPS},
@@ -645,6 +697,7 @@ def main():
         b5 = bl5_metric(ocs, dev)
         big = bl2_large_batch_metric(ocs, dev) if world == 1 else None
         one = bl2_single_state_metric(ocs, dev) if world == 1 else None
+        rot = bl2_rotated_metric(ocs, dev, batch) if world == 1 else None
         ssr = strong_scaling_readiness(ocs, dev) if world == 1 and not use_dist else None
         if rank == 0:
             line["fb_sweep"] = fb
@@ -654,6 +707,8 @@ def main():
                 line["other_configs"]["BL-2 problem at batch 65536 (lane mapping, HBM-bound regime)"] = big
             if one:
                 line["other_configs"]["BL-2 shapes with one state (TestOCProblem, nAug = 2)"] = one
+            if rot:
+                line["other_configs"]["BL-2 pass pair over 3 rotating buffer sets (no reuse across steps: HBM, not Infinity Cache)"] = rot
             if ssr:
                 line["other_configs"]["strong-scaling readiness (8-GPU shard sizes on one GPU)"] = ssr
     if rank == 0:

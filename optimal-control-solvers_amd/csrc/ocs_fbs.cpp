@@ -3,6 +3,7 @@
 // convergence state, the whole batch advances sweep by sweep until no instance is active.
 #include "ocs_trace.hpp"
 #include <cstdio>
+#include <cstdlib>
 #include <string>
 #include "ocs_handles.hpp"
 
@@ -540,7 +541,18 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       HIP_TRY(hipHostMalloc((void**)&f->h_nact, sizeof(int) * (size_t)nsw));
       f->h_nact_cap = nsw;
     }
-    while (f->wevents.size() < 2) {
+    // How many sweeps are enqueued beyond the one the host waits for.  The gate of a sweep is read on the device in stream
+    // order, so any depth is correct; a sweep enqueued after the last live one costs two kernels that return at once.  With
+    // depth 1 the host had one sweep (~180 us) to wake up, read the count and enqueue the next: enough on an idle host, not on
+    // a busy one (a late host leaves the GPU idle between dependent kernels); depth 2 gives it two.  OCS_FBS_DEPTH overrides.
+    static const int depth_env = [] {
+      const char* e = getenv("OCS_FBS_DEPTH");
+      const int d = e ? atoi(e) : 0;
+      return d >= 1 && d <= 8 ? d : 2;
+    }();
+    const int depth = std::min(depth_env, std::max(1, nsw - 1));
+    const int nev = depth + 1;
+    while ((int)f->wevents.size() < nev) {
       hipEvent_t ev;
       HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
       f->wevents.push_back(ev);
@@ -562,7 +574,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
         LAUNCH_TRY(launch_costate_met(pd, gd, batch, xaug, nAug, tb.PR, p->d_lb.d(), p->d_ub.d(), opt->uRelTol,
                                       opt->uAbsTol, sweep, status, mc, dslots + (sweep - 1), lam, s, gate));
         HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipEventRecord(f->wevents[sweep & 1], s));
+        HIP_TRY(hipEventRecord(f->wevents[sweep % nev], s));
         return OCS_OK;
       }
       FwdOpts fo;
@@ -578,15 +590,15 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
                                     mc, dslots + (sweep - 1), s, 0, gate));
       HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
-      HIP_TRY(hipEventRecord(f->wevents[sweep & 1], s));
+      HIP_TRY(hipEventRecord(f->wevents[sweep % nev], s));
       return OCS_OK;
     };
-    OCS_TRY(enqueue(1));
+    for (int k = 1; k <= std::min(depth, nsw); ++k) OCS_TRY(enqueue(k));
     for (int sweep = 1; sweep <= nsw; ++sweep) {
-      if (sweep < nsw) OCS_TRY(enqueue(sweep + 1));
-      HIP_TRY(hipEventSynchronize(f->wevents[sweep & 1]));
+      if (sweep + depth <= nsw) OCS_TRY(enqueue(sweep + depth));
+      HIP_TRY(hipEventSynchronize(f->wevents[sweep % nev]));
       nactive = f->h_nact[sweep - 1];
-      if (nactive == 0) break;  // the sweep already enqueued finds its gate closed
+      if (nactive == 0) break;  // the sweeps already enqueued find their gates closed
     }
     spec_done = true;
   }

@@ -5,10 +5,12 @@
 
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -52,12 +54,13 @@ inline int fail(int code, const char* fmt, ...) {
   } while (0)
 
 inline int require_device() {
-  static int state = 0;  // 0 unknown, 1 ok, -1 none
-  if (state == 0) {
+  static std::once_flag once;   // (reachable from the worker threads of ocs_multi_*)
+  static int state = -1;        // 1 ok, -1 none
+  std::call_once(once, [] {
     int n = 0;
     hipError_t e = hipGetDeviceCount(&n);
     state = (e == hipSuccess && n > 0) ? 1 : -1;
-  }
+  });
   if (state < 0)
     return fail(OCS_ERR_NO_DEVICE, "no HIP device: libocs has no CPU fallback, an MI355X is required");
   return OCS_OK;
@@ -89,9 +92,30 @@ struct DevBuf {
 // ------------------------------------------------------------------------------------
 // handles
 // ------------------------------------------------------------------------------------
+// Globally unique: the integrator tables are cached under (problem pointer, version), and problems are created and
+// re-parametrised concurrently from the worker threads of ocs_multi_*.
 inline unsigned long long next_version() {
-  static unsigned long long c = 1;
-  return c++;
+  static std::atomic<unsigned long long> c{1};
+  return c.fetch_add(1, std::memory_order_relaxed);
+}
+
+// The HIP current device is per host thread.  Every handle records the device it was created on; entry points that
+// switch devices (ocs_multi_*) restore the caller's on every return path through this guard.
+struct DeviceGuard {
+  int prev = -1;
+  DeviceGuard() {
+    if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+  }
+  ~DeviceGuard() {
+    if (prev >= 0) (void)hipSetDevice(prev);
+  }
+  DeviceGuard(const DeviceGuard&) = delete;
+  DeviceGuard& operator=(const DeviceGuard&) = delete;
+};
+
+inline int current_device_or(int dflt) {
+  int d = dflt;
+  return hipGetDevice(&d) == hipSuccess ? d : dflt;
 }
 
 }  // namespace ocs
@@ -100,6 +124,7 @@ struct ocs_problem_s {
   using DevBuf = ocs::DevBuf;
   using Functor = ocs::Functor;
   int id = 0, nS = 0, nC = 0;
+  int device = -1;              // HIP device current when the handle was created (-1: created without a device)
   Functor functor = Functor::Logistic;
   ocs::UserModule* user = nullptr;  // hipRTC module of a user-supplied problem
   std::vector<double> par;      // functor order
@@ -122,6 +147,7 @@ void ocs_fbs_state_free(ocs_fbs_state* s);
 struct ocs_integrator_s {
   using DevBuf = ocs::DevBuf;
   ocs_fbs_state* fbs = nullptr;
+  int device = -1;   // HIP device current when the handle was created
   int rec_stride = 8;  // doubles per step record of the bound problem
   bool uniform = false;  // all steps of the grid have the same size
   hipEvent_t tc_event = nullptr;   // recorded behind the kernels that build TC / TU / REC / RECS ...

@@ -125,6 +125,55 @@ def timed_max_over_ranks(fn, reps: int, sync=None):
     return dt / reps
 
 
+def prewarm(fn, seconds: float, sync=None, chunk: int = 1):
+    """Untimed calls of fn() for at least `seconds` of wall time (an idle GPU sits at low clocks for a few hundred ms;
+    a count-based warm-up of a ms-scale leg does not bring them up).  Returns the number of calls."""
+    import time
+    n, t0 = 0, time.perf_counter()
+    while True:
+        for _ in range(chunk):
+            fn()
+        n += chunk
+        if sync:
+            sync()
+        if time.perf_counter() - t0 >= seconds:
+            return n
+
+
+def timed_reps_max_over_ranks(fn, reps: int, sync=None, inner: int = 1):
+    """Per-repetition wall times (seconds per call of fn): every repetition is `inner` calls bracketed by sync() on both
+    sides; under a process group a barrier precedes the first repetition and every repetition's time is the maximum over
+    ranks.  The caller reports min / median / max and the list, so that one stalled repetition shows as what it is."""
+    import time
+    on = collectives_on()
+    if sync:
+        sync()
+    if on:
+        dist.barrier()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        for _ in range(inner):
+            fn()
+        if sync:
+            sync()
+        ts.append((time.perf_counter() - t0) / inner)
+    if on:
+        t = torch.tensor(ts, dtype=torch.float64, device=_reduce_device())
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        ts = [float(v) for v in t.tolist()]
+    return ts
+
+
+def spread(ts, unit_scale: float = 1e3, digits: int = 4):
+    """min / median / max / per-rep list of a list of times (default: seconds -> ms)."""
+    a = sorted(ts)
+    n = len(a)
+    med = a[n // 2] if n % 2 else 0.5 * (a[n // 2 - 1] + a[n // 2])
+    r = lambda v: round(v * unit_scale, digits)
+    return {"min": r(a[0]), "median": r(med), "max": r(a[-1]), "reps": n, "per_rep": [r(v) for v in ts]}, med
+
+
 def _reduce_device():
     if dist.get_backend() == "nccl":
         return torch.device("cuda", torch.cuda.current_device())

@@ -130,17 +130,26 @@ def fb_sweep(prob, x0, tspan, options=None):
             "J": float(r["J"][0])}
 
 
-def fb_sweep_dev(prob, integ, x0, options=None, u0grid=None, u0err=None):
-    """Device path: x0 [nS][B] torch tensor; returns device tensors (batch-minor)."""
+def fb_sweep_dev(prob, integ, x0, options=None, u0grid=None, u0err=None, out=None):
+    """Device path: x0 [nS][B] torch tensor; returns device tensors (batch-minor).  `out`: the dict an earlier call
+    with the same shapes returned -- its tensors are written again instead of allocating new ones (a loop of solves
+    then performs no allocation at all)."""
     o, _ = _options(options)
     N, B = integ.nSTEPS, x0.shape[-1]
     dev = x0.device
-    xaug = torch.empty((N + 1, prob.nAug, B), dtype=torch.float64, device=dev)
-    lam = torch.empty((N + 1, prob.nS, B), dtype=torch.float64, device=dev)
-    uI = torch.empty((o.nINTERP_PTS, prob.nC, B), dtype=torch.float64, device=dev)
-    J = torch.empty(B, dtype=torch.float64, device=dev)
-    sweeps = torch.zeros(B, dtype=torch.int32, device=dev)
-    mc = torch.empty((o.nSWEEPS, B), dtype=torch.float64, device=dev)
+    if out is not None:
+        xaug, lam, uI, J, sweeps, mc = (out[k] for k in ("xaug", "lam", "u", "J", "sweeps", "maxChange"))
+        if (tuple(xaug.shape) != (N + 1, prob.nAug, B) or tuple(lam.shape) != (N + 1, prob.nS, B)
+                or tuple(uI.shape) != (o.nINTERP_PTS, prob.nC, B) or tuple(mc.shape) != (o.nSWEEPS, B)
+                or J.numel() != B or sweeps.numel() != B or sweeps.dtype != torch.int32):
+            raise ValueError("fb_sweep_dev: `out` does not have the shapes of this call")
+    else:
+        xaug = torch.empty((N + 1, prob.nAug, B), dtype=torch.float64, device=dev)
+        lam = torch.empty((N + 1, prob.nS, B), dtype=torch.float64, device=dev)
+        uI = torch.empty((o.nINTERP_PTS, prob.nC, B), dtype=torch.float64, device=dev)
+        J = torch.empty(B, dtype=torch.float64, device=dev)
+        sweeps = torch.zeros(B, dtype=torch.int32, device=dev)
+        mc = torch.empty((o.nSWEEPS, B), dtype=torch.float64, device=dev)
     status = check(lib.ocs_fb_sweep_dev(integ._h, prob._h, B, _dptr(x0), C.byref(o), _dptr(u0grid), _dptr(u0err),
                                         _dptr(xaug), _dptr(lam), _dptr(uI), _dptr(J), C.c_void_p(sweeps.data_ptr()),
                                         _dptr(mc), _stream()))
