@@ -312,8 +312,10 @@ int ocs_fb_sweep_path(ocs_integrator g);
 
 /* ---- the batch axis over the GPUs of one node (the reference has no batch axis and no parallelism:
  * every entry point integrates one trajectory, tests/solve_test_problem.m:37) ----
- * ocs_multi_create: devices[n] (NULL: 0 .. n-1), one stream per device and ONE RCCL communicator over them
- * (ncclCommInitAll).  A call below cuts the batch into contiguous blocks (block k = ocs_multi_shard(m, batch, k) goes to
+ * ocs_multi_create: devices[n] (NULL: 0 .. n-1), one stream and one persistent host thread per device and ONE RCCL
+ * communicator over them (ncclCommInitAll; librccl.so is loaded at run time -- without it, or if the communicator cannot
+ * be created, the same reductions run on the host over the per-device partial results).  The caller's current HIP
+ * device is the same before and after every ocs_multi_* call.  A call below cuts the batch into contiguous blocks (block k = ocs_multi_shard(m, batch, k) goes to
  * device k; sizes differ by at most one), runs the one-device host entry point of the same name on every block
  * concurrently -- no data-path exchange -- and ends with the O(1)-size reductions on the devices: all-reduce(SUM) of
  * [sum J, count] and all-gather of (min J, argmin) over RCCL.  Arrays are the MATLAB-shaped host arrays of the
@@ -344,6 +346,36 @@ int ocs_multi_nlp_objective(ocs_multi m, const ocs_integrator *g, const ocs_prob
 int ocs_multi_fb_sweep(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, int batch, const double *x0,
                        const ocs_fbs_options *opt, const double *u0grid, const double *u0err, double *x, double *lam,
                        double *uInterp, double *J, int *sweeps, double *maxChange, double *stats);
+
+/* 1 if the handle holds an RCCL communicator, 0 if its reductions run on the host (librccl.so missing, ncclCommInitAll
+ * failed, OCS_MULTI_NO_RCCL=1; ocs_last_error() then says which) */
+int ocs_multi_has_communicator(ocs_multi m);
+/* Device-resident blocks (the iteration loop of functions/single_shooting.m:114,137-150 keeps its iterates on the devices):
+ * every array argument is an array of n DEVICE pointers, entry k on device ocs_multi_device(m, k), batch-minor exactly as
+ * the one-device _dev entry point of the same name takes it, for a block of batch[k] trajectories (blocks need not be
+ * equal; block k holds the global indices [sum_{j<k} batch[j], ...)).  Nothing is copied or transposed.  The kernels are
+ * enqueued on the per-device streams (ocs_multi_stream) and the call returns without waiting for them; with reduce != 0
+ * the reductions -- all-reduce(SUM) of [sum J, count], all-gather of (min J, argmin) over RCCL -- are enqueued behind the
+ * kernels on the same streams, and ocs_multi_stats waits for them and returns {sum of the finite J, their number, min J,
+ * global index of the minimum} (ocs_multi_fb_sweep_dev: over the converged instances).  ocs_multi_synchronize waits for
+ * all streams.  ocs_multi_fb_sweep_dev returns when every device's sweep loop has ended (the loop reads the count of
+ * active instances after every sweep); u0 is the default lower bound (fb_sweep.m:23). */
+int ocs_multi_stream(ocs_multi m, int k, void **stream);   /* hipStream_t of device k */
+int ocs_multi_synchronize(ocs_multi m);
+int ocs_multi_stats(ocs_multi m, double *stats);
+int ocs_multi_compute_states_dev(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, const int *batch,
+                                 const double *const *x0, const double *const *u, double *const *x, double *const *J,
+                                 int reduce);
+int ocs_multi_compute_adjoints_dev(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, const int *batch,
+                                   const double *const *u, const double *const *lamT, double *const *lam,
+                                   double *const *dJdu);
+int ocs_multi_nlp_objective_dev(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, const ocs_control *c,
+                                const int *batch, double *const *x0, const double *const *v, int nFree,
+                                const int *FreeInitStates, double *const *J, double *const *dJdv, int reduce);
+int ocs_multi_fb_sweep_dev(ocs_multi m, const ocs_integrator *g, const ocs_problem *p, const int *batch,
+                           const double *const *x0, const ocs_fbs_options *opt, double *const *xaug, double *const *lam,
+                           double *const *uInterp, double *const *J, int *const *sweeps, double *const *maxChange,
+                           int reduce);
 
 /* layout helpers: MATLAB (trajectory-major, [batch][cols][rows]) <-> batch-minor ([cols][rows][batch]),
  * device pointers, rows*cols doubles per trajectory. */

@@ -103,6 +103,18 @@ _SIG = {
     "ocs_multi_nlp_objective": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int, dp, dp, C.c_int, ip,
                                           dp, dp, dp]),
     "ocs_multi_fb_sweep": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.c_int, dp, vp, dp, dp, dp, dp, dp, dp, ip, dp, dp]),
+    "ocs_multi_has_communicator": (C.c_int, [vp]),
+    "ocs_multi_stream": (C.c_int, [vp, C.c_int, C.POINTER(vp)]),
+    "ocs_multi_synchronize": (C.c_int, [vp]),
+    "ocs_multi_stats": (C.c_int, [vp, dp]),
+    "ocs_multi_compute_states_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), ip, C.POINTER(vp), C.POINTER(vp),
+                                               C.POINTER(vp), C.POINTER(vp), C.c_int]),
+    "ocs_multi_compute_adjoints_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), ip, C.POINTER(vp), C.POINTER(vp),
+                                                 C.POINTER(vp), C.POINTER(vp)]),
+    "ocs_multi_nlp_objective_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), ip, C.POINTER(vp),
+                                              C.POINTER(vp), C.c_int, ip, C.POINTER(vp), C.POINTER(vp), C.c_int]),
+    "ocs_multi_fb_sweep_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), ip, C.POINTER(vp), vp, C.POINTER(vp),
+                                         C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int]),
     "ocs_copy_dev": (C.c_int, [vp, vp, C.c_long, vp]),
     "ocs_to_batch_minor_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "ocs_to_traj_major_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

@@ -121,6 +121,9 @@ int ocs_problem_set_batch_params(ocs_problem p, int batch, const int* param_inde
   if (p->user && (npar > 16 || user_rowsep(p->user)))
     return fail(OCS_ERR_UNSUPPORTED, "user problems with more than 16 parameters or given as row functions read the "
                                      "shared parameter block only: no per-trajectory parameters");
+  if (p->user && p->user->tcoef_hooks)
+    return fail(OCS_ERR_UNSUPPORTED, "the problem source defines ocs_tcoef / ocs_cc_tcoef, whose values are tabulated once per "
+                                     "grid point from the SHARED parameter block: no per-trajectory parameters");
   const unsigned tcmask = functor_tc_param_mask(p->functor, p->nS);
   unsigned mask = 0;
   std::vector<double> pb((size_t)npar * batch, 0.0);

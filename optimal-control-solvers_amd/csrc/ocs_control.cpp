@@ -22,6 +22,7 @@ struct ocs_control_s {
                       // (k_forward_fc / k_backward_fc) only
   bool dense = false;  // more than half of B is non-zero and nBasis <= 32: register-resident dense kernels
   bool uploaded = false;
+  int device = -1;   // HIP device that owns the handle's memory (set at the first upload)
   hipStream_t stream = nullptr;
   DevBuf d_v, d_u, d_dJdu, d_dJdv, d_stage, d_x0, d_J, d_idx;
 };
@@ -101,6 +102,7 @@ static void pchip_slopes(int n, const double* x, const double* y, double* d) {
 static int upload_control(ocs_control_s* c) {
   if (c->uploaded) return OCS_OK;
   OCS_TRY(require_device());
+  if (c->device < 0) c->device = current_device_or(-1);
   const int nB = c->nBasis, nT = c->nT;
   std::vector<int> colptr(nT + 1, 0), row, rowptr(nB + 1, 0), col;
   std::vector<double> cval, rval;
@@ -553,6 +555,7 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
 }  // extern "C"
 // the objectives of the last host ocs_nlp_objective on this handle, on its device (ocs_multi.cpp's reductions)
 const double* ocs_control_device_J(const ocs_control_s* c) { return c ? c->d_J.d() : nullptr; }
+int ocs_control_device_id(const ocs_control_s* c) { return c ? c->device : -1; }
 extern "C" {
 
 int ocs_control_set_fusion(ocs_control c, int mode) {

@@ -177,12 +177,14 @@ struct ocs_integrator_s {
 
 struct ocs_control_s;
 const double* ocs_control_device_J(const ocs_control_s* c);   // ocs_control.cpp
+int ocs_control_device_id(const ocs_control_s* c);             // device owning the handle's memory, -1 before the first use
 
 namespace ocs {
 
 inline int upload_problem(ocs_problem_s* p) {
   if (p->uploaded) return OCS_OK;
   OCS_TRY(require_device());
+  if (p->device < 0) p->device = current_device_or(-1);   // the device that owns the handle's memory from here on
   OCS_TRY(p->d_ps.ensure(sizeof(double) * p->par.size()));
   HIP_TRY(hipMemcpy(p->d_ps.p, p->par.data(), sizeof(double) * p->par.size(), hipMemcpyHostToDevice));
   OCS_TRY(p->d_lb.ensure(sizeof(double) * p->nC));
@@ -211,6 +213,7 @@ inline ProblemDesc describe(const ocs_problem_s* p) {
 inline int upload_grid(ocs_integrator_s* g) {
   if (g->grid_uploaded) return OCS_OK;
   OCS_TRY(require_device());
+  if (g->device < 0) g->device = current_device_or(-1);
   const int N = g->N;
   std::vector<double> HT((size_t)4 * N);
   for (int i = 0; i < N; ++i) {  // the divisions the reference performs per step, done once in IEEE fp64

@@ -161,7 +161,7 @@ int launch_copy8(const double* src, double* dst, size_t n, hipStream_t s);
 // number of non-finite entries of v[0..n) is added to *count (device int)
 int launch_count_nonfinite(const double* v, int n, int* count, hipStream_t s);
 // out[0..3] = {sum of the finite J[i], their number, min J, lo + index of the minimum (-1 if none is finite)}
-int launch_objective_stats(const double* J, int n, int lo, double* out, hipStream_t s);
+int launch_objective_stats(const double* J, int n, int lo, double* out, hipStream_t s, const int* mask = nullptr);
 // status[i] = OCS_NUM_NONFINITE if J[i] is NaN/Inf, else 0
 int launch_traj_status(const double* J, int n, int* status, hipStream_t s);
 

@@ -161,14 +161,23 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
     std::vector<char> code;
     std::vector<std::string> lowered;
   };
+  // One slot per source; its mutex is held while the source compiles, so concurrent creators of the same problem (the
+  // worker threads of ocs_multi_*, one per device) wait for ONE compilation instead of running it N times.
+  struct Slot {
+    std::mutex mu;
+    std::shared_ptr<const Compiled> cc;
+  };
   static std::mutex cache_mu;
-  static std::unordered_map<std::string, std::shared_ptr<const Compiled>> cache;
-  std::shared_ptr<const Compiled> cc;
+  static std::unordered_map<std::string, std::shared_ptr<Slot>> cache;
+  std::shared_ptr<Slot> slot;
   {
     std::lock_guard<std::mutex> lk(cache_mu);
-    auto it = cache.find(src);
-    if (it != cache.end()) cc = it->second;
+    std::shared_ptr<Slot>& sl = cache[src];
+    if (!sl) sl = std::make_shared<Slot>();
+    slot = sl;
   }
+  std::unique_lock<std::mutex> slot_lk(slot->mu);
+  std::shared_ptr<const Compiled> cc = slot->cc;
   if (!cc) {
     hiprtcProgram prog = nullptr;
     if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 11, hdr_src, hdr_name) != 0) {
@@ -214,9 +223,9 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
     r->GetCode(prog, fresh->code.data());
     r->DestroyProgram(&prog);
     cc = fresh;
-    std::lock_guard<std::mutex> lk(cache_mu);
-    cache.emplace(src, cc);
+    slot->cc = cc;
   }
+  slot_lk.unlock();
   UserModule* m = new UserModule();
   m->nS = nS;
   m->nC = nC;
@@ -225,6 +234,7 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   m->rowsep = rowsep;
   m->vector = vec;
   m->fold = fold;
+  m->tcoef_hooks = strstr(user_src, "OCS_USER_TCOEF") != nullptr || strstr(user_src, "OCS_USER_CC_TCOEF") != nullptr;
   m->chunk = user_chunk(nS);
   m->code = cc->code;
   const std::vector<std::string>& lowered = cc->lowered;
@@ -299,6 +309,7 @@ int ocs_problem_create_from_source(ocs_problem* out, const char* source, int nS,
   p->nC = nC;
   p->functor = Functor::User;
   p->user = m;
+  p->device = current_device_or(-1);   // the code object is loaded on the device current now
   p->par.assign(params, params + nparams);
   if (p->par.empty()) p->par.push_back(0.0);
   p->user2func.resize(nparams);

@@ -38,6 +38,7 @@ enum UserKernel : int {
 struct UserModule {
   int nS = 0, nC = 0, npar = 0, chunk = 4;
   bool has_cc = false, loaded = false, rowsep = false, vector = false, fold = false;
+  bool tcoef_hooks = false;   // the source defines OCS_USER_TCOEF / OCS_USER_CC_TCOEF (coefficients tabulated from the shared parameters)
   std::vector<char> code;
   hipModule_t mod = nullptr;
   hipFunction_t fn[UK_COUNT] = {};

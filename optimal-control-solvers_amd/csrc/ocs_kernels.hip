@@ -390,12 +390,14 @@ int launch_traj_status(const double* J, int n, int* status, hipStream_t s) {
 }
 
 // one workgroup: the post-reductions of a shard's objectives (ocs_multi.cpp)
-__global__ __launch_bounds__(256) void k_objective_stats(const double* __restrict__ J, int n, int lo, double* __restrict__ out) {
+// (mask: optional, entries <= 0 are left out -- the sweep index of fb_sweep, 0 = not converged)
+__global__ __launch_bounds__(256) void k_objective_stats(const double* __restrict__ J, int n, int lo, double* __restrict__ out,
+                                                         const int* __restrict__ mask) {
   __shared__ double ss[256], sc[256], sm[256], si[256];
   double sum = 0.0, cnt = 0.0, mn = INFINITY, am = -1.0;
   for (int i = threadIdx.x; i < n; i += 256) {
     const double v = J[i];
-    if (isfinite(v)) {
+    if (isfinite(v) && (!mask || mask[i] > 0)) {
       sum += v;
       cnt += 1.0;
       if (v < mn) {
@@ -426,8 +428,8 @@ __global__ __launch_bounds__(256) void k_objective_stats(const double* __restric
     out[3] = si[0];
   }
 }
-int launch_objective_stats(const double* J, int n, int lo, double* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_objective_stats, dim3(1), dim3(256), 0, s, J, n, lo, out);
+int launch_objective_stats(const double* J, int n, int lo, double* out, hipStream_t s, const int* mask) {
+  hipLaunchKernelGGL(k_objective_stats, dim3(1), dim3(256), 0, s, J, n, lo, out, mask);
   return hip_rc(hipGetLastError());
 }
 

@@ -68,7 +68,10 @@ struct BufP2 {
     return BufP2{__builtin_amdgcn_make_buffer_rsrc(p, 0, kNumRecP2, 0x00020000)};
   }
   __device__ inline void st(double v, unsigned voff, unsigned soff) const {
-    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_p2, v), r, voff, soff, 0);
+#ifndef OCS_P2_X_ST_AUX
+#define OCS_P2_X_ST_AUX 0   // cache policy of the state rows of x (tuning builds: scripts/build_variants.sh)
+#endif
+    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u_p2, v), r, voff, soff, OCS_P2_X_ST_AUX);
   }
   // non-temporal: for rows nobody reads back soon (the running-objective row: the adjoint pass reads the state rows only)
   __device__ inline void st_nt(double v, unsigned voff, unsigned soff) const {

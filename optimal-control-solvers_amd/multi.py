@@ -19,6 +19,13 @@ def _harr(objs):
     return (C.c_void_p * len(objs))(*[o._h for o in objs])
 
 
+def _parr(tensors):
+    """array of device pointers, one per device (None -> NULL array)"""
+    if tensors is None:
+        return None
+    return (C.c_void_p * len(tensors))(*[None if t is None else t.data_ptr() for t in tensors])
+
+
 class MultiDevice:
     def __init__(self, devices=None, n=None):
         """devices: list of HIP device ids (default: the first n, default all)."""
@@ -32,13 +39,77 @@ class MultiDevice:
         check(lib.ocs_multi_create(C.byref(self._h), arr, len(self.devices)))
 
     def __del__(self):
-        if getattr(self, "_h", None):
+        if getattr(self, "_h", None) and lib is not None:   # (lib is None while the interpreter shuts down)
             lib.ocs_multi_destroy(self._h)
             self._h = None
 
     @property
     def size(self):
         return lib.ocs_multi_size(self._h)
+
+    @property
+    def has_communicator(self):
+        """True: the reductions run over RCCL; False: on the host (librccl missing / OCS_MULTI_NO_RCCL=1 / init failure)."""
+        return check(lib.ocs_multi_has_communicator(self._h)) == 1
+
+    def stream(self, k):
+        """hipStream_t (as int) the kernels of block k are enqueued on."""
+        st = C.c_void_p()
+        check(lib.ocs_multi_stream(self._h, k, C.byref(st)))
+        return st.value or 0
+
+    def synchronize(self):
+        check(lib.ocs_multi_synchronize(self._h))
+
+    def stats(self):
+        """The reductions a *_dev call with reduce=True enqueued: waits for them."""
+        st = np.empty(4)
+        check(lib.ocs_multi_stats(self._h, _p(st)))
+        return self._stats(st)
+
+    # ---- device-resident blocks: lists of torch tensors, entry k on device self.devices[k], batch-minor -----------------
+    @staticmethod
+    def _counts(tensors):
+        return (C.c_int * len(tensors))(*[int(t.shape[-1]) for t in tensors])
+
+    def compute_states_dev(self, integs, probs, x0, u, x, J, reduce=False):
+        """x0[k] [nS][B_k], u[k] [2N+1][nC][B_k] -> x[k] [N+1][nAug][B_k] (or None), J[k] [B_k]; asynchronous."""
+        return check(lib.ocs_multi_compute_states_dev(self._h, _harr(integs), _harr(probs), self._counts(x0), _parr(x0),
+                                                      _parr(u), _parr(x), _parr(J), int(bool(reduce))))
+
+    def compute_adjoints_dev(self, integs, probs, u, lam, dJdu, lamT=None):
+        return check(lib.ocs_multi_compute_adjoints_dev(self._h, _harr(integs), _harr(probs), self._counts(u), _parr(u),
+                                                        _parr(lamT), _parr(lam), _parr(dJdu)))
+
+    def nlp_objective_dev(self, integs, probs, ctrls, x0, v, J, dJdv, FreeInitStates=(), reduce=False):
+        fis = (C.c_int * len(FreeInitStates))(*FreeInitStates) if len(FreeInitStates) else None
+        return check(lib.ocs_multi_nlp_objective_dev(self._h, _harr(integs), _harr(probs), _harr(ctrls), self._counts(v),
+                                                     _parr(x0), _parr(v), len(FreeInitStates), fis, _parr(J), _parr(dJdv),
+                                                     int(bool(reduce))))
+
+    def fb_sweep_dev(self, integs, probs, x0, options=None, reduce=False):
+        """One fb_sweep per device block, concurrently; returns per-device dicts of tensors as sweep.fb_sweep_dev."""
+        import torch
+        from .sweep import _options
+        o, _ = _options(options)
+        outs = []
+        for k, x0k in enumerate(x0):
+            N, B, dev = integs[k].nSTEPS, x0k.shape[-1], x0k.device
+            nS, nC = probs[k].nS, probs[k].nC
+            outs.append({"xaug": torch.empty((N + 1, nS + 1, B), dtype=torch.float64, device=dev),
+                         "lam": torch.empty((N + 1, nS, B), dtype=torch.float64, device=dev),
+                         "u": torch.empty((o.nINTERP_PTS, nC, B), dtype=torch.float64, device=dev),
+                         "J": torch.empty(B, dtype=torch.float64, device=dev),
+                         "sweeps": torch.zeros(B, dtype=torch.int32, device=dev),
+                         "maxChange": torch.empty((o.nSWEEPS, B), dtype=torch.float64, device=dev)})
+        import torch as _t
+        _t.cuda.synchronize()   # the outputs were allocated on torch's stream, the kernels run on the handle's streams
+        rc = check(lib.ocs_multi_fb_sweep_dev(self._h, _harr(integs), _harr(probs), self._counts(x0), _parr(x0), C.byref(o),
+                                              *[_parr([r[n] for r in outs]) for n in ("xaug", "lam", "u", "J", "sweeps", "maxChange")],
+                                              int(bool(reduce))))
+        for r in outs:
+            r["status"] = rc
+        return outs
 
     def shard(self, batch, k):
         lo, hi = C.c_int(), C.c_int()

@@ -20,7 +20,7 @@ __device__ inline double sum(dbl2 a) { return a.x + a.y; }
 __device__ inline double mk(double s, double) { return s; }
 __device__ inline dbl2 mk(double s, dbl2) { dbl2 o; o.x = s; o.y = s + 1.0; return o; }
 
-template <int G, int V, bool NT>
+template <int G, int V, bool NT, bool NTL = false, bool PF = false>
 __global__ __launch_bounds__(1024) void k_stream(int N, int B, const double* __restrict__ X, const double* __restrict__ U,
                                                  double* __restrict__ LAM, double* __restrict__ D) {
   typedef typename Vec<V>::T T;
@@ -31,15 +31,27 @@ __global__ __launch_bounds__(1024) void k_stream(int N, int B, const double* __r
   const int row = rg * G + r;
   const size_t traj = (size_t)tile * TPW + (size_t)tl * V;
   const int nsb = (N + 63) / 64;
-  for (int sb = nsb - 1; sb >= 0; --sb) {
+  auto ldv = [&](const double* p) -> T { return NTL ? __builtin_nontemporal_load((const T*)p) : *(const T*)p; };
+  T xv[4], u0[4], u1[4], xn[4], un0[4], un1[4];
+  auto loads = [&](int sb, T* a, T* b, T* c) {
     const int i0 = sb * 64 + wave * 4;
-    T xv[4], u0[4], u1[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const int i = i0 + j < N ? i0 + j : N - 1;
-      xv[j] = *(const T*)(X + ((size_t)i * 5 + row) * B + traj);
-      u0[j] = *(const T*)(U + (size_t)(2 * i) * B + traj);
-      u1[j] = *(const T*)(U + (size_t)(2 * i + 1) * B + traj);
+      a[j] = ldv(X + ((size_t)i * 5 + row) * B + traj);
+      b[j] = ldv(U + (size_t)(2 * i) * B + traj);
+      c[j] = ldv(U + (size_t)(2 * i + 1) * B + traj);
+    }
+  };
+  if (PF) loads(nsb - 1, xn, un0, un1);
+  for (int sb = nsb - 1; sb >= 0; --sb) {
+    const int i0 = sb * 64 + wave * 4;
+    if (PF) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { xv[j] = xn[j]; u0[j] = un0[j]; u1[j] = un1[j]; }
+      if (sb > 0) loads(sb - 1, xn, un0, un1);
+    } else {
+      loads(sb, xv, u0, u1);
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -60,18 +72,18 @@ __global__ __launch_bounds__(1024) void k_stream(int N, int B, const double* __r
   }
 }
 
-template <int G, int V, bool NT>
+template <int G, int V, bool NT, bool NTL = false, bool PF = false>
 void run(const char* name, int N, int B, int ROT, std::vector<double*>& X, std::vector<double*>& U, std::vector<double*>& L,
          std::vector<double*>& D) {
   constexpr int TPW = 64 / G * V, RG = 4 / G;
   const int grid = B / TPW * RG;
   hipEvent_t e0, e1;
   CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-  for (int k = 0; k < 30; ++k) k_stream<G, V, NT><<<grid, 1024>>>(N, B, X[k % ROT], U[k % ROT], L[k % ROT], D[k % ROT]);
+  for (int k = 0; k < 30; ++k) k_stream<G, V, NT, NTL, PF><<<grid, 1024>>>(N, B, X[k % ROT], U[k % ROT], L[k % ROT], D[k % ROT]);
   CK(hipDeviceSynchronize());
   const int K = 90;
   CK(hipEventRecord(e0));
-  for (int k = 0; k < K; ++k) k_stream<G, V, NT><<<grid, 1024>>>(N, B, X[k % ROT], U[k % ROT], L[k % ROT], D[k % ROT]);
+  for (int k = 0; k < K; ++k) k_stream<G, V, NT, NTL, PF><<<grid, 1024>>>(N, B, X[k % ROT], U[k % ROT], L[k % ROT], D[k % ROT]);
   CK(hipEventRecord(e1)); CK(hipDeviceSynchronize());
   float ms; CK(hipEventElapsedTime(&ms, e0, e1));
   const double us = ms * 1e3 / K;
@@ -91,7 +103,11 @@ int main(int argc, char** argv) {
     }
     run<4, 1, true>("G=4 (4 x 128 B per instruction), nt stores", N, B, ROT, X, U, L, D);
     run<4, 1, false>("G=4, default stores", N, B, ROT, X, U, L, D);
+    run<4, 1, true, true>("G=4, nt stores, nt loads", N, B, ROT, X, U, L, D);
+    run<4, 1, true, false, true>("G=4, nt stores, loads one superblock ahead", N, B, ROT, X, U, L, D);
+    run<4, 1, true, true, true>("G=4, nt stores, nt loads one superblock ahead", N, B, ROT, X, U, L, D);
     run<2, 1, true>("G=2 (2 x 256 B), nt stores", N, B, ROT, X, U, L, D);
+    run<2, 1, true, true, true>("G=2, nt stores, nt loads one superblock ahead", N, B, ROT, X, U, L, D);
     run<1, 1, true>("G=1 (512 B), nt stores", N, B, ROT, X, U, L, D);
     run<1, 2, true>("G=1, 16 B per lane (1 KiB), nt stores", N, B, ROT, X, U, L, D);
     run<4, 2, true>("G=4, 16 B per lane (4 x 256 B), nt stores", N, B, ROT, X, U, L, D);
