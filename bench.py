@@ -503,8 +503,9 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2, shard=True):
     return {"value": batch * 2 * N / dt, "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
             "batch": batch, "batch_per_gpu": nloc, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3,
             "ms_adjoint": tb * 1e3, "ms_pass_pair_max_over_ranks": dt * 1e3, "ms_pass_pair_spread": sp5,
-            "roofline": {"bound": "mfma", "kernel": ("k_lq4_backward (adjoint + dJdu, both legs; four waves per 16 trajectories, "
-                                                     "products split over K), this rank" if nloc <= 4096 else
+            "roofline": {"bound": "mfma", "kernel": ("k_lq_backward in time-parallel chunks (pass Z + carries + pass X, both legs; one wave "
+                                                     "per 16 trajectories and chunk; 14 stage products per step instead of 7 -- "
+                                                     "the flops counted are the algorithm's 7), this rank" if nloc <= 4096 else
                                                      "k_lq2_backward (adjoint + dJdu, both legs; two waves per 16 "
                                                      "trajectories), this rank") if nloc <= 8192 else
                                                     "k_lq_backward (adjoint + dJdu, both legs; one wave per 16 trajectories), this rank",

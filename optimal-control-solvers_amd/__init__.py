@@ -22,3 +22,10 @@ from .solvers import (nlp_objective, nlp_objective_dev, single_shooting, single_
 from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, fb_sweep_path, compute_x_lam, compute_x_lam_J  # noqa: F401
 from . import distributed  # noqa: F401
 from .multi import MultiDevice  # noqa: F401
+
+
+def make_from_symbolic(*args, **kwargs):
+    """prob = make_from_symbolic(symObjective, symStateRHS, nStates, nControls, params, bounds)
+    (functions/make_from_symbolic.m); SymPy is imported on first use (symbolic.py)."""
+    from .symbolic import make_from_symbolic as _m
+    return _m(*args, **kwargs)

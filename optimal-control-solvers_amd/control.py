@@ -145,13 +145,40 @@ class PWConstantControl(_BoundedControl):
 
 class ChebyshevControl(Control):
     """Control/ChebyshevControl.m: obj = ChebyshevControl(t, nControlBasis, nControls).
-    The reference class has no compute_nlp_bounds and an empty compute_lincon (:51-53): bounds are
-    not enforced by this parametrisation (documented in DESIGN.md)."""
+    The reference class has no compute_nlp_bounds, and its compute_lincon is declared with an EMPTY body (:51-53:
+    single_shooting.m:106-107 would fail on it): u = v*B itself is unclamped (nlp_objective evaluates it as such).
+    `compute_lincon` below fills that hook in the way its signature asks for -- the control bounds as linear
+    inequalities on the coefficients at grid points -- so that single_shooting can honour ControlBounds with this basis."""
     kind = CONTROL_CHEBYSHEV
 
-    def __init__(self, t, nControlBasis, nControls):
+    def __init__(self, t, nControlBasis, nControls, lincon_points=None):
         super().__init__(t, nControlBasis, nControls)
         self.nControlBasis = int(nControlBasis)
+        self.lincon_points = lincon_points   # None: every grid point; an int n: n points spread evenly over the grid
+
+    def compute_lincon(self, ControlBounds):
+        """[A, b] = compute_lincon(obj, ControlBounds)   ChebyshevControl.m:51 (empty in the reference): A v <= b with
+        lb_c <= u_c(t_j) = sum_k v(c + nC (k-1)) B(k, j) <= ub_c at the chosen grid points t_j (v: control index fastest,
+        compute_u :34-38).  Rows with an infinite bound are left out."""
+        cb = _f(ControlBounds, (self.nControls, 2))
+        B = self.B                                           # nBasis x nT
+        nT, nB, nC = B.shape[1], self.nBasis, self.nControls
+        cols = np.arange(nT) if self.lincon_points is None else np.unique(
+            np.round(np.linspace(0, nT - 1, int(self.lincon_points))).astype(int))
+        rows, rhs = [], []
+        for c in range(nC):
+            for j in cols:
+                a = np.zeros(nB * nC)
+                a[c::nC] = B[:, j]
+                if np.isfinite(cb[c, 1]):
+                    rows.append(a)
+                    rhs.append(cb[c, 1])
+                if np.isfinite(cb[c, 0]):
+                    rows.append(-a)
+                    rhs.append(-cb[c, 0])
+        if not rows:
+            return np.zeros((0, nB * nC)), np.zeros(0)
+        return np.vstack(rows), np.asarray(rhs, dtype=np.float64)
 
     @property
     def controlPts(self):

@@ -300,6 +300,7 @@ int ocs_integrator_destroy(ocs_integrator g) {
   if (!g) return OCS_OK;
   if (g->leg2) ocs_integrator_destroy(g->leg2);
   if (g->fbs) ocs_fbs_state_free(g->fbs);
+  if (g->lqws) lq_workspace_free(g->lqws);
   g->d_ustar.release();
   g->d_lam2.release();
   if (g->stream) (void)hipStreamDestroy(g->stream);
@@ -399,6 +400,7 @@ int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const d
     OCS_TRY(bind_problem(g2, p, batch, s));
     OCS_TRY(g->d_lam2.ensure(sizeof(double) * (size_t)(p->nS + 1) * batch));
     BwdOpts o2;
+    o2.mapping = g2->mapping;
     o2.uconst = true;
     o2.lam0 = g->d_lam2.d();
     LAUNCH_TRY(launch_backward(describe(p), describe(g2), batch, g2->ck, g->d_ustar.d(), nullptr, nullptr, nullptr,

@@ -147,6 +147,7 @@ void ocs_fbs_state_free(ocs_fbs_state* s);
 struct ocs_integrator_s {
   using DevBuf = ocs::DevBuf;
   ocs_fbs_state* fbs = nullptr;
+  ocs::LqWorkspace* lqws = nullptr;   // time-parallel LQ passes: chunk matrices of the bound problem + scratch
   int device = -1;   // HIP device current when the handle was created
   int rec_stride = 8;  // doubles per step record of the bound problem
   bool uniform = false;  // all steps of the grid have the same size
@@ -207,6 +208,7 @@ inline ProblemDesc describe(const ocs_problem_s* p) {
   d.lb = p->d_lb.d();
   d.ub = p->d_ub.d();
   d.user = p->user;
+  d.version = p->version;
   return d;
 }
 
@@ -247,6 +249,7 @@ inline GridDesc describe(const ocs_integrator_s* g) {
   d.REC = g->d_REC.d() ? g->d_REC.d() + (size_t)rec_pad_host() * g->rec_stride : nullptr;
   d.RECS = g->d_RECS.d() ? g->d_RECS.d() + scan_recs_front() : nullptr;
   d.uniform = g->uniform;
+  d.lqws = const_cast<LqWorkspace**>(&g->lqws);
   return d;
 }
 

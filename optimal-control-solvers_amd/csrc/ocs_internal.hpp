@@ -10,6 +10,9 @@ namespace ocs {
 enum class Functor : int { Logistic = 1, LQ = 3, User = 100 };
 struct UserModule;  // hipRTC-compiled user problem (ocs_jit.hpp)
 
+struct LqWorkspace;   // chunk matrices and scratch of the time-parallel LQ passes (ocs_lq_kernels.hip), owned by an integrator
+void lq_workspace_free(LqWorkspace* w);
+
 struct ProblemDesc {
   Functor functor;
   int nS, nC;
@@ -20,6 +23,7 @@ struct ProblemDesc {
   const double* lb;   // device: control lower bounds [nC]
   const double* ub;   // device: control upper bounds [nC]
   const UserModule* user = nullptr;  // set for Functor::User
+  unsigned long long version = 0;    // of the handle's device-visible parameters (cache key of tables derived from them)
 };
 
 struct GridDesc {
@@ -31,6 +35,7 @@ struct GridDesc {
   double* REC;        // device: [N][rec_stride(NTC)] per-step records {h,h/2,h/6,h/3,tcA,tcM,tcB}
   double* RECS = nullptr;  // device: compact zero-padded records of the scan kernels (record of step 0), or nullptr
   bool uniform = false;    // every step has the same size (bitwise): kernels may keep h, h/2, h/6, h/3 in registers
+  LqWorkspace** lqws = nullptr;  // where the integrator keeps the workspace of the time-parallel LQ passes (created on first use)
 };
 
 // Device-native layouts (batch-minor): x0 [nS][B], u [2N+1][nC][B], x [N+1][nAug][B],

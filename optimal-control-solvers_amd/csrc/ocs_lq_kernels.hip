@@ -23,6 +23,7 @@
 #include "ocs_rk4_kernels.hpp"
 #include "ocs_scan_kernel.hpp"   // Buf: raw buffer accesses with scalar offsets
 #include <cstdlib>
+#include <vector>
 #ifdef OCS_LQ_STAMPS
 #include <cstdio>
 #include <vector>
@@ -66,6 +67,11 @@ struct LQArgs {
   double* dJdu;         // [2N+1][nC][B] or null
   double* lam0;         // [nAug][B] or null
   long long* dbg;       // diagnostic builds only: [blocks][8] cycle sums
+  // time-parallel passes (k_lq_forward / k_lq_backward with CH != 0): blockIdx.y = chunk c, steps [c L, min(N, (c+1) L))
+  int L;                // steps per chunk
+  const double* cs;     // chunk start values [C][nS][B]: the state at the chunk's first node / the costate at its last node
+  double* ce;           // CH = 1: chunk end values [C][nS][B] (state at the last node from cs / costate at the first node from 0)
+  double* cj;           // CH = 2: forward: chunk objective sums [C][B]; adjoint: k1 half of the chunk's first node column [C][nC][B]
 };
 
 // D = A(16x4) * B(4x16) + C on one wave; a: lane (g,i) holds A[i][g]; b: lane (g,n) holds B[g][n];
@@ -179,7 +185,10 @@ struct LQCore {
 // ---------------------------------------------------------------------------------------
 // forward pass   RK4Integrator.m:28-56
 // ---------------------------------------------------------------------------------------
-template <int RT, bool OUT_X, bool UCONST>
+// CH (time-parallel passes, see "chunked passes" below): 0 the whole horizon from x0; 1 the chunk blockIdx.y from the
+// start state cs[c], no objective, no trajectory: only the state at the chunk's last node -> ce[c]; 2 the chunk from
+// cs[c] with every output of its steps, the running objective counted from the chunk's first node (its total -> cj[c]).
+template <int RT, bool OUT_X, bool UCONST, int CH = 0>
 __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
   constexpr int KS = 4 * RT;
   using Rec = StepRec<1>;
@@ -189,13 +198,18 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
   const size_t B = (size_t)a.batch;
   const int nS = a.nS, nC = a.nC, N = a.N;
   const size_t nAugB = (size_t)(nS + 1) * B;
+  const int ch = CH ? (int)blockIdx.y : 0;
+  const int i0 = CH ? ch * a.L : 0, i1 = CH ? (i0 + a.L < N ? i0 + a.L : N) : N;
 
   LQCore<RT> P;
   P.load(a.ps, nS, nC, g, n);
 
   double y[KS], yc = 0.0;  // xK(:,1,1) = [x0; 0]   :33
+  {
+    const double* ys = CH ? a.cs + (size_t)ch * nS * B : a.x0;
 #pragma unroll
-  for (int m = 0; m < KS; ++m) y[m] = (4 * m + g < nS) ? a.x0[(size_t)(4 * m + g) * B + b] : 0.0;
+    for (int m = 0; m < KS; ++m) y[m] = (4 * m + g < nS) ? ys[(size_t)(4 * m + g) * B + b] : 0.0;
+  }
 
   // (global accesses through raw buffer descriptors built per column on the scalar unit, per-lane byte offsets fixed for
   //  the pass: no 64-bit vector address arithmetic on the pipe the matrix instructions need -- see k_lq2_forward)
@@ -210,11 +224,11 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
     for (int m = 0; m < KS; ++m) bx.st0(y[m], vrow[m], 0);
     bx.st0(yc, vcost, 0);
   };
-  store_x(0);
+  if (!CH || ch == 0) store_x(0);
 
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
-  const double* up = a.u + (size_t)(uact ? g : 0) * B + b;  // u(:,1) of this lane's control row
+  const double* up = a.u + (UCONST ? 0 : (size_t)(2 * i0) * ustride) + (size_t)(uact ? g : 0) * B + b;  // u(:, 2 i0 + 1) of this lane's control row
   const unsigned vu = (unsigned)(((size_t)(uact ? g : 0) * B + b) * 8), us8 = (unsigned)(ustride * 8);
   double uA = UCONST ? (uact ? a.u[g] : 0.0) : (uact ? *up : 0.0);
   d4 buA[RT], buM[RT], buB[RT];
@@ -224,14 +238,14 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
     for (int rt = 0; rt < RT; ++rt) buM[rt] = buB[rt] = buA[rt];
   }
 
-  const double* recp = a.REC;
+  const double* recp = a.REC + (size_t)i0 * rec_stride(1);
   Rec cur = load_rec<1>(recp);
   double uM = uA, uB = uA;
   if (!UCONST) {
     uM = uact ? up[ustride] : 0.0;
     uB = uact ? up[2 * ustride] : 0.0;
   }
-  for (int i = 0; i < N; ++i) {
+  for (int i = i0; i < i1; ++i) {
     // next step's uniform record and control samples are requested now and consumed a step later
     recp += rec_stride(1);
     const Rec nxt = load_rec<1>(recp);  // the table is padded past step N-1
@@ -247,23 +261,24 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
     }
     double F1[KS], F2[KS], F3[KS], F4[KS], Y[KS];
     P.Fx(y, buA, F1);                                                         // :37
-    double cs = P.cost_part(y, uA, cur.tcA[0]);
+    double cs = 0.0;
+    if (CH != 1) cs = P.cost_part(y, uA, cur.tcA[0]);
 #pragma unroll
     for (int m = 0; m < KS; ++m) Y[m] = __builtin_fma(cur.hh, F1[m], y[m]);   // :40
     P.Fx(Y, buM, F2);                                                         // :41
-    cs += 2.0 * P.cost_part(Y, uM, cur.tcM[0]);
+    if (CH != 1) cs += 2.0 * P.cost_part(Y, uM, cur.tcM[0]);
 #pragma unroll
     for (int m = 0; m < KS; ++m) Y[m] = __builtin_fma(cur.hh, F2[m], y[m]);   // :44
     P.Fx(Y, buM, F3);                                                         // :45
-    cs += 2.0 * P.cost_part(Y, uM, cur.tcM[0]);
+    if (CH != 1) cs += 2.0 * P.cost_part(Y, uM, cur.tcM[0]);
 #pragma unroll
     for (int m = 0; m < KS; ++m) Y[m] = __builtin_fma(cur.h, F3[m], y[m]);    // :48
     P.Fx(Y, buB, F4);                                                         // :49
-    cs += P.cost_part(Y, uB, cur.tcB[0]);
+    if (CH != 1) cs += P.cost_part(Y, uB, cur.tcB[0]);
 #pragma unroll
     for (int m = 0; m < KS; ++m)                                              // :50
       y[m] = __builtin_fma(cur.h6, (F1[m] + 2.0 * F2[m]) + (2.0 * F3[m] + F4[m]), y[m]);
-    yc = __builtin_fma(cur.h6, sum_over_g(cs), yc);
+    if (CH != 1) yc = __builtin_fma(cur.h6, sum_over_g(cs), yc);
     store_x(i + 1);
     cur = nxt;
     uA = uB;
@@ -272,13 +287,26 @@ __global__ __launch_bounds__(64) void k_lq_forward(const LQArgs a) {
 #pragma unroll
     for (int rt = 0; rt < RT; ++rt) buA[rt] = buB[rt];
   }
-  if (g == 0) a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;  // J = x(end,end)   :55
+  if (CH == 0) {
+    if (g == 0) a.J[b] = a.Jadd ? a.Jadd[b] + yc : yc;  // J = x(end,end)   :55
+  } else if (CH == 1) {
+    double* ye = a.ce + (size_t)ch * nS * B;
+#pragma unroll
+    for (int m = 0; m < KS; ++m)
+      if (4 * m + g < nS && b0 < a.batch) ye[(size_t)(4 * m + g) * B + b] = y[m];
+  } else {
+    if (g == 0 && b0 < a.batch) a.cj[(size_t)ch * B + b] = yc;
+  }
 }
 
 // ---------------------------------------------------------------------------------------
 // adjoint pass   RK4Integrator.m:59-121
 // ---------------------------------------------------------------------------------------
-template <int RT, bool OUT_LAM, bool OUT_DJDU, bool UCONST>
+// CH: 0 the whole horizon from lamT; 1 the chunk blockIdx.y from a zero costate at its last node (the objective row keeps
+// its constant value), no outputs but the costate at the chunk's first node -> ce[c] (the part of the affine chunk map
+// lam_lo = M' lam_hi + b that does not depend on lam_hi); 2 the chunk from cs[c] with every output of its steps; the k1
+// half of its first node column of dJdu, which belongs to the column the chunk below writes, goes to cj[c].
+template <int RT, bool OUT_LAM, bool OUT_DJDU, bool UCONST, int CH = 0>
 __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
   constexpr int KS = 4 * RT;
   using Rec = StepRec<1>;
@@ -286,7 +314,10 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
   const int b0 = blockIdx.x * 16 + n;
   const int b = b0 < a.batch ? b0 : a.batch - 1;
   const size_t B = (size_t)a.batch;
-  const int nS = a.nS, nC = a.nC, N = a.N;
+  const int nS = a.nS, nC = a.nC;
+  const int ch = CH ? (int)blockIdx.y : 0;
+  const int i0 = CH ? ch * a.L : 0;
+  const int N = CH ? (i0 + a.L < a.N ? i0 + a.L : a.N) : a.N;   // the last node of the pass / of the chunk
   const size_t nAugB = (size_t)(nS + 1) * B;
 
   LQCore<RT> P;
@@ -324,8 +355,14 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
   };
 
   double lam[KS], lamc;  // lam(:,end) = lamT   :69; the last row of dFdx_times_vec is 0, so lam(end,:) is constant
+  if (CH == 2) {
+    const double* ls = a.cs + (size_t)ch * nS * B;
 #pragma unroll
-  for (int m = 0; m < KS; ++m) lam[m] = (a.lamT && 4 * m + g < nS) ? a.lamT[(size_t)(4 * m + g) * B + b] : 0.0;
+    for (int m = 0; m < KS; ++m) lam[m] = (4 * m + g < nS) ? ls[(size_t)(4 * m + g) * B + b] : 0.0;
+  } else {
+#pragma unroll
+    for (int m = 0; m < KS; ++m) lam[m] = (CH == 0 && a.lamT && 4 * m + g < nS) ? a.lamT[(size_t)(4 * m + g) * B + b] : 0.0;
+  }
   lamc = a.lamT ? a.lamT[(size_t)nS * B + b] : 1.0;
 
   unsigned vrow[KS];   // (raw buffer descriptors per column: see k_lq_forward)
@@ -339,7 +376,7 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
     for (int m = 0; m < KS; ++m) bl.st0(lam[m], vrow[m], 0);
     bl.st0(lamc, vlamc, 0);
   };
-  store_lam(N);
+  if (!CH || N == a.N) store_lam(N);
 
   const bool uact = g < nC;
   const size_t ustride = (size_t)nC * B;
@@ -370,7 +407,7 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
   }
   double eA0 = cur.tcA[0];
 
-  for (int i = N - 1; i >= 0; --i) {
+  for (int i = N - 1; i >= i0; --i) {
     // requests for step i-1 (consumed at the end of this iteration)
     recp -= rec_stride(1);
     const Rec nxt = load_rec<1>(recp);  // the table is padded before step 0
@@ -446,9 +483,19 @@ __global__ __launch_bounds__(64) void k_lq_backward(const LQArgs a) {
   }
   if (OUT_DJDU) {  // first column: B(t_1, y_1, u_1)' k1_1   :100-101   (uB now holds u(:,1))
     const double d0 = but_times(k1c) + 2.0 * eA0 * P.R * uB * k1lc;
-    if (uact) dq[0] = d0;
+    if (CH == 2 && ch > 0) {   // the k1 half of column 2 i0: the chunk below writes that column (its k4 half)
+      if (uact && b0 < a.batch) a.cj[((size_t)ch * nC + g) * B + b] = d0;
+    } else if (uact) {
+      dq[0] = d0;
+    }
   }
-  if (a.lam0) {
+  if (CH == 1) {
+    double* le = a.ce + (size_t)ch * nS * B;
+#pragma unroll
+    for (int m = 0; m < KS; ++m)
+      if (4 * m + g < nS && b0 < a.batch) le[(size_t)(4 * m + g) * B + b] = lam[m];
+  }
+  if (a.lam0 && CH != 1 && (CH == 0 || ch == 0)) {
 #pragma unroll
     for (int m = 0; m < KS; ++m)
       if (4 * m + g < nS) a.lam0[(size_t)(4 * m + g) * B + b] = lam[m];
@@ -1540,6 +1587,280 @@ __global__ void k_lq_eval(int which, int k, int nS, int nC, const double* __rest
 }
 
 // ---------------------------------------------------------------------------------------
+// chunked ("time-parallel") passes for small batches
+// ---------------------------------------------------------------------------------------
+// The dynamics are linear with a Jacobian shared by the batch, so the RK4 step of Integrator/RK4Integrator.m:35-52 is an
+// affine map x_{i+1} = P_i x_i + g_i(u) whose matrix P_i = sum_{k<=4} (h_i A)^k / k! depends on the grid alone, and the
+// discrete adjoint of :72-89 is lam_i = P_i' lam_{i+1} + c_i (c_i: the objective row's share, which reads the stage
+// states and the constant lam(end)).  A small batch (BASELINE configs[4] gives each of 8 GPUs 1024 trajectories = 64
+// groups of 16) leaves most SIMDs without a wave and is bound by the 2 N dependent steps of a lone wave.  Here the horizon
+// is cut into C chunks of L steps, and a wave integrates ONE chunk of one group:
+//   pass Z   every chunk from a zero start (state pass: with its controls; adjoint pass: with the objective's share) ->
+//            the constant z_c of the chunk map  x_hi = M_c x_lo + z_c  /  lam_lo = M_c' lam_hi + b_c;   M_c = prod P_i
+//   carry    x at every chunk's first node: x_{c+1} = M_c x_c + z_c, C small matrix-vector products per trajectory
+//   pass X   every chunk from its true start, with all outputs of its steps -- RK4Integrator.m's lines as in the serial kernel
+//   fix-up   the running objective restarts at every chunk: the sums of the chunks below are added to the cost row; a node
+//            column of dJdu at a chunk boundary is the sum of a k4 half (chunk below) and a k1 half (chunk above)
+// M_c is not formed from powers of A: pass Z runs once per (grid, problem) on the unit vectors with zero control
+// (the same instruction sequence the trajectories see).  Work per step doubles, the dependent chain shrinks C-fold; used
+// while groups x C <= one wave per SIMD.  Any grid (the h_i enter through the step records as everywhere else).
+struct LqWorkspace {
+  // chunk matrices of one (grid, problem): MT [C][nS][nU] with M_c[r][k] at (c nS + r) nU + k
+  const double* key_ps = nullptr;
+  const double* key_rec = nullptr;
+  unsigned long long key_version = 0;
+  int key_C = 0, key_N = 0, key_nS = 0;
+  double* MT = nullptr;
+  size_t MT_cap = 0;
+  // per-call scratch: cs, ce [C][nS][B]; cj [C][max(1, nC)][B]; off [C + 1][B]
+  double *cs = nullptr, *ce = nullptr, *cj = nullptr, *off = nullptr, *zero_u = nullptr, *unit = nullptr;
+  size_t cs_cap = 0, ce_cap = 0, cj_cap = 0, off_cap = 0, unit_cap = 0;
+};
+void lq_workspace_free(LqWorkspace* w) {
+  if (!w) return;
+  for (double* q : {w->MT, w->cs, w->ce, w->cj, w->off, w->zero_u, w->unit})
+    if (q) (void)hipFree(q);
+  delete w;
+}
+static int lq_ensure(double*& q, size_t& cap, size_t n) {
+  if (n <= cap) return 0;
+  if (q) (void)hipFree(q);
+  q = nullptr;
+  cap = 0;
+  const hipError_t e = hipMalloc((void**)&q, n * sizeof(double));
+  if (e != hipSuccess) return (int)e;
+  cap = n;
+  return 0;
+}
+
+// carries through the chunk maps.  Thread (b, rg) owns rows 8 rg .. 8 rg + 7 of trajectory b (block: 64 x 4).
+// TRANS = false (state pass):   out[0] = start; out[c+1] = M_c out[c] + add[c], c = 0 .. C-2
+// TRANS = true  (adjoint pass): out[C-1] = start (or zero); out[c-1] = M_c' out[c] + add[c], c = C-1 .. 1;
+//                               last (optional, [nS][B]) = M_0' out[0] + add[0]
+template <bool TRANS>
+__global__ __launch_bounds__(256) void k_lq_carry(int nS, int nU, int B, int C, const double* __restrict__ MT,
+                                                  const double* __restrict__ start, const double* __restrict__ add,
+                                                  double* out, double* last) {
+  // the chunk matrix and the block's 64 current vectors live in LDS: an iteration is one round of global loads (the
+  // next matrix, the next constants) and 32 x 8 multiply-adds per thread from LDS, not 32 dependent global round trips
+  __shared__ double Ms[32 * 32];
+  __shared__ double xs[32 * 64];
+  const int tl = threadIdx.x & 63, rg = threadIdx.x >> 6;
+  const int b = blockIdx.x * 64 + tl;
+  const bool live = b < B;
+  const size_t SB = (size_t)nS * B;
+  const int first = TRANS ? C - 1 : 0;
+  for (int r = 8 * rg; r < 8 * rg + 8; ++r) {
+    const double v = (live && r < nS && start) ? start[(size_t)r * B + b] : 0.0;
+    xs[r * 64 + tl] = v;
+    if (live && r < nS) out[(size_t)first * SB + (size_t)r * B + b] = v;
+  }
+  const int nsteps = TRANS ? (last ? C : C - 1) : C - 1;
+  for (int it = 0; it < nsteps; ++it) {
+    const int c = TRANS ? C - 1 - it : it;           // the chunk whose map is applied
+    const int dst = TRANS ? c - 1 : c + 1;           // (-1: `last`)
+    const double* M = MT + (size_t)c * nS * nU;
+    for (int e = threadIdx.x; e < 32 * 32; e += 256) {   // Ms[r][k] = M_c[r][k] (TRANS: M_c[k][r]), zero outside nS x nS
+      const int r = e >> 5, k = e & 31;
+      Ms[e] = (r < nS && k < nS) ? (TRANS ? M[(size_t)k * nU + r] : M[(size_t)r * nU + k]) : 0.0;
+    }
+    double acc[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = 8 * rg + q;
+      acc[q] = (live && r < nS) ? add[(size_t)c * SB + (size_t)r * B + b] : 0.0;
+    }
+    __syncthreads();   // Ms and xs complete
+#pragma unroll 8
+    for (int k = 0; k < 32; ++k) {
+      const double xk = xs[k * 64 + tl];
+#pragma unroll
+      for (int q = 0; q < 8; ++q) acc[q] = __builtin_fma(Ms[(8 * rg + q) * 32 + k], xk, acc[q]);
+    }
+    __syncthreads();   // everybody has read xs and Ms
+    double* o = dst >= 0 ? out + (size_t)dst * SB : last;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int r = 8 * rg + q;
+      xs[r * 64 + tl] = (r < nS) ? acc[q] : 0.0;
+      if (live && r < nS) o[(size_t)r * B + b] = acc[q];
+    }
+  }
+}
+
+// off[0] = 0, off[c+1] = off[c] + cj[c]; J = (Jadd +) off[C]  -- the value the cost row's last entry gets below
+__global__ void k_lq_cost_prefix(int B, int C, const double* __restrict__ cj, double* __restrict__ off,
+                                 const double* __restrict__ Jadd, double* __restrict__ J) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double s = 0.0;
+  off[b] = 0.0;
+  for (int c = 0; c < C; ++c) {
+    s += cj[(size_t)c * B + b];
+    off[(size_t)(c + 1) * B + b] = s;
+  }
+  J[b] = Jadd ? Jadd[b] + s : s;
+}
+// x(end, col) += off[chunk of col] for the columns above the first chunk (blockIdx.y + L + 1 = col)
+__global__ void k_lq_cost_fix(int B, int nS, int N, int L, const double* __restrict__ off, double* __restrict__ x) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int col = blockIdx.y + L + 1;
+  if (b >= B || col > N) return;
+  const int c = (col - 1) / L;
+  double* q = x + ((size_t)col * (nS + 1) + nS) * B + b;
+  // (the last column: off[c] + local is the sum k_lq_cost_prefix formed for J, bit for bit)
+  *q = off[(size_t)c * B + b] + *q;
+}
+// dJdu(:, 2 c L + 1) += the k1 half the chunk above left in cj[c], c = 1 .. C-1
+__global__ void k_lq_djdu_fix(int B, int nC, int L, int C, const double* __restrict__ cj, double* __restrict__ dJdu) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.y + 1, g = blockIdx.z;
+  if (b >= B || c >= C) return;
+  double* q = dJdu + ((size_t)(2 * c * L) * nC + g) * B + b;
+  *q += cj[((size_t)c * nC + g) * B + b];
+}
+
+__global__ void k_lq_set_row(int B, double* __restrict__ dst, const double* __restrict__ src) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b < B) dst[b] = src ? src[b] : 1.0;
+}
+
+// how many chunks: groups x C = 2048 waves, two per SIMD (measured at 1024 trajectories, 2 x 4000 steps, pass pair: 1024 waves
+// 7.8 ms, 2048 6.6 ms, 4096 6.6 ms; the X passes hold at most two waves per SIMD in registers); at most 64 chunks; chunks of
+// at least 32 steps when chosen automatically (2 when the mapping is requested: tests, tuning).  OCS_LQ_CHUNK_WAVES
+// overrides the wave target.
+static bool lq_chunk_forced(int mapping) {
+  static const int env = [] {
+    const char* e = getenv("OCS_LQ_MAP");
+    return e ? atoi(e) : 0;
+  }();
+  return mapping == MAP_SCAN || (mapping == MAP_AUTO && env == 5);
+}
+static int lq_chunks(int batch, int N, int mapping) {
+  static const int target = [] {
+    const char* e = getenv("OCS_LQ_CHUNK_WAVES");
+    const int v = e ? atoi(e) : 0;
+    return v > 0 ? v : 2048;
+  }();
+  const int groups = (batch + 15) / 16, minlen = lq_chunk_forced(mapping) ? 2 : 32;
+  int C = target / groups;
+  if (C > 64) C = 64;
+  if (C > N / minlen) C = N / minlen;
+  return C < 2 ? 1 : C;
+}
+// automatic selection: up to 4096 trajectories (C >= 8).  Measured, nS = 32, nC = 4, 2 x 4000 steps, pass pair: 1024 trajectories
+// 6.6 ms (four-wave kernels 28.5), 2048: ~12 (28.6), 4096: 21-23 (28.6); at 8192 the doubled work costs what the shorter chains
+// gain (two-wave kernels 30.3 ms)
+static bool lq_chunked(int batch, int N, int mapping) {
+  static const int env = [] {
+    const char* e = getenv("OCS_LQ_MAP");
+    return e ? atoi(e) : 0;
+  }();
+  if (lq_chunk_forced(mapping)) return lq_chunks(batch, N, mapping) >= 2;
+  if (mapping != MAP_AUTO || env != 0) return false;
+  return lq_chunks(batch, N, mapping) >= 8;
+}
+
+template <int RT>
+static int lq_chunk_matrices(LqWorkspace* w, const ProblemDesc& p, const GridDesc& g, int C, int L, hipStream_t s) {
+  const int nS = p.nS, nU = 16 * RT;
+  if (w->MT && w->key_ps == p.ps && w->key_version == p.version && w->key_rec == g.REC && w->key_C == C && w->key_N == g.N &&
+      w->key_nS == nS)
+    return 0;
+  int rc;
+  if ((rc = lq_ensure(w->MT, w->MT_cap, (size_t)C * nS * nU))) return rc;
+  if ((rc = lq_ensure(w->unit, w->unit_cap, (size_t)C * nS * nU))) return rc;
+  if (!w->zero_u) {
+    if (hipMalloc((void**)&w->zero_u, 8 * sizeof(double)) != hipSuccess) return (int)hipErrorOutOfMemory;
+    (void)hipMemsetAsync(w->zero_u, 0, 8 * sizeof(double), s);
+  }
+  // start states: the unit vectors, for every chunk ([C][nS][nU], trajectory j starts at e_j)
+  std::vector<double> I((size_t)C * nS * nU, 0.0);
+  for (int c = 0; c < C; ++c)
+    for (int r = 0; r < nS; ++r) I[((size_t)c * nS + r) * nU + r] = 1.0;
+  if (hipMemcpyAsync(w->unit, I.data(), I.size() * sizeof(double), hipMemcpyHostToDevice, s) != hipSuccess) return (int)hipErrorUnknown;
+  if (hipStreamSynchronize(s) != hipSuccess) return (int)hipErrorUnknown;   // (I is a host temporary)
+  LQArgs a{};
+  a.N = g.N; a.batch = nU; a.nS = nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
+  a.u = w->zero_u; a.L = L; a.cs = w->unit; a.ce = w->MT;
+  k_lq_forward<RT, false, true, 1><<<dim3(nU / 16, C), dim3(64), 0, s>>>(a);
+  w->key_ps = p.ps; w->key_version = p.version; w->key_rec = g.REC; w->key_C = C; w->key_N = g.N; w->key_nS = nS;
+  return hip_rc_lq(hipGetLastError());
+}
+
+template <int RT>
+static int lq_forward_chunked(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
+                              double* x, double* J, const FwdOpts& o, hipStream_t s) {
+  LqWorkspace*& w = *g.lqws;
+  if (!w) w = new LqWorkspace();
+  const int N = g.N, nS = p.nS, nC = p.nC, nU = 16 * RT;
+  const int C0 = lq_chunks(batch, N, o.mapping), L = (N + C0 - 1) / C0, C = (N + L - 1) / L;
+  const size_t B = (size_t)batch;
+  int rc;
+  if ((rc = lq_chunk_matrices<RT>(w, p, g, C, L, s))) return rc;
+  if ((rc = lq_ensure(w->cs, w->cs_cap, (size_t)C * nS * B))) return rc;
+  if ((rc = lq_ensure(w->ce, w->ce_cap, (size_t)C * nS * B))) return rc;
+  if ((rc = lq_ensure(w->cj, w->cj_cap, (size_t)C * (nC > 1 ? nC : 1) * B))) return rc;
+  if ((rc = lq_ensure(w->off, w->off_cap, (size_t)(C + 1) * B))) return rc;
+  LQArgs a{};
+  a.N = N; a.batch = batch; a.nS = nS; a.nC = nC; a.REC = g.REC; a.ps = p.ps;
+  a.x0 = x0; a.u = u; a.x = x; a.J = J; a.Jadd = o.Jadd; a.L = L;
+  const dim3 grid((batch + 15) / 16, C), block(64);
+  // pass Z: every chunk from a zero state (cs of the carries is not read: zeros through a memset)
+  if (hipMemsetAsync(w->cs, 0, (size_t)C * nS * B * sizeof(double), s) != hipSuccess) return (int)hipErrorUnknown;
+  a.cs = w->cs; a.ce = w->ce;
+  if (o.uconst) k_lq_forward<RT, false, true, 1><<<grid, block, 0, s>>>(a);
+  else k_lq_forward<RT, false, false, 1><<<grid, block, 0, s>>>(a);
+  k_lq_carry<false><<<dim3((batch + 63) / 64), dim3(256), 0, s>>>(nS, nU, batch, C, w->MT, x0, w->ce, w->cs, nullptr);
+  // pass X
+  a.cj = w->cj; a.ce = nullptr;
+  if (o.uconst) k_lq_forward<RT, true, true, 2><<<grid, block, 0, s>>>(a);
+  else if (x) k_lq_forward<RT, true, false, 2><<<grid, block, 0, s>>>(a);
+  else k_lq_forward<RT, false, false, 2><<<grid, block, 0, s>>>(a);
+  k_lq_cost_prefix<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, C, w->cj, w->off, o.Jadd, J);
+  if (x && N > L) k_lq_cost_fix<<<dim3((batch + 255) / 256, N - L), dim3(256), 0, s>>>(batch, nS, N, L, w->off, x);
+  return hip_rc_lq(hipGetLastError());
+}
+
+template <int RT>
+static int lq_backward_chunked(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
+                               const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s) {
+  LqWorkspace*& w = *g.lqws;
+  if (!w) w = new LqWorkspace();
+  const int N = g.N, nS = p.nS, nC = p.nC, nU = 16 * RT;
+  const int C0 = lq_chunks(batch, N, o.mapping), L = (N + C0 - 1) / C0, C = (N + L - 1) / L;
+  const size_t B = (size_t)batch;
+  int rc;
+  if ((rc = lq_chunk_matrices<RT>(w, p, g, C, L, s))) return rc;
+  if ((rc = lq_ensure(w->cs, w->cs_cap, (size_t)C * nS * B))) return rc;
+  if ((rc = lq_ensure(w->ce, w->ce_cap, (size_t)C * nS * B))) return rc;
+  if ((rc = lq_ensure(w->cj, w->cj_cap, (size_t)C * (nC > 1 ? nC : 1) * B))) return rc;
+  LQArgs a{};
+  a.N = N; a.batch = batch; a.nS = nS; a.nC = nC; a.REC = g.REC; a.ps = p.ps;
+  a.xck = xck; a.u = u; a.lamT = lamT; a.L = L;
+  const dim3 grid((batch + 15) / 16, C), block(64);
+  // pass Z: the objective's share of every chunk map (zero costate at the chunk's last node)
+  a.ce = w->ce;
+  if (o.uconst) k_lq_backward<RT, false, false, true, 1><<<grid, block, 0, s>>>(a);
+  else k_lq_backward<RT, false, false, false, 1><<<grid, block, 0, s>>>(a);
+  // carries from the last node down; with a constant control (the tail leg of RK4InfiniteIntegrator.m:27-30) only
+  // lam(:,1) is wanted, which is the carry below the first chunk
+  double* last = nullptr;
+  if (o.uconst) last = o.lam0;
+  k_lq_carry<true><<<dim3((batch + 63) / 64), dim3(256), 0, s>>>(nS, nU, batch, C, w->MT, lamT, w->ce, w->cs, last);
+  if (o.uconst) {   // the constant objective row of lam(:,1)
+    k_lq_set_row<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, o.lam0 + (size_t)nS * B, lamT ? lamT + (size_t)nS * B : nullptr);
+    return hip_rc_lq(hipGetLastError());
+  }
+  a.ce = nullptr; a.cs = w->cs; a.cj = w->cj; a.lam = lam; a.dJdu = dJdu; a.lam0 = o.lam0;
+  if (lam && dJdu) k_lq_backward<RT, true, true, false, 2><<<grid, block, 0, s>>>(a);
+  else if (lam) k_lq_backward<RT, true, false, false, 2><<<grid, block, 0, s>>>(a);
+  else k_lq_backward<RT, false, true, false, 2><<<grid, block, 0, s>>>(a);
+  if (dJdu && C > 1) k_lq_djdu_fix<<<dim3((batch + 255) / 256, C - 1, nC), dim3(256), 0, s>>>(batch, nC, L, C, w->cj, dJdu);
+  return hip_rc_lq(hipGetLastError());
+}
+
+// ---------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------
 bool lq_supported(int nS, int nC) { return nS >= 1 && nS <= 32 && nC >= 1 && nC <= 4; }
@@ -1588,6 +1909,8 @@ int launch_forward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const 
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
   a.x0 = x0; a.u = u; a.x = x; a.J = J; a.Jadd = o.Jadd;
+  if (g.lqws && lq_chunked(batch, g.N, o.mapping))
+    return p.nS <= 16 ? lq_forward_chunked<1>(p, g, batch, x0, u, x, J, o, s) : lq_forward_chunked<2>(p, g, batch, x0, u, x, J, o, s);
   if (p.nS <= 16) {
     run_lq_forward<1>(a, o.uconst, s);
   } else if (lq_four_wave(batch, o.mapping)) {
@@ -1649,6 +1972,9 @@ int launch_backward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
   a.xck = xck; a.u = u; a.lamT = lamT; a.lam = lam; a.dJdu = dJdu; a.lam0 = o.lam0;
+  if (g.lqws && lq_chunked(batch, g.N, o.mapping))
+    return p.nS <= 16 ? lq_backward_chunked<1>(p, g, batch, xck, u, lamT, lam, dJdu, o, s)
+                      : lq_backward_chunked<2>(p, g, batch, xck, u, lamT, lam, dJdu, o, s);
   if (p.nS <= 16) {
     run_lq_backward<1>(a, o.uconst, s);
   } else if (lq_four_wave(batch, o.mapping)) {

@@ -134,6 +134,10 @@ constexpr int kScanRec = 16;       // doubles per record: {h, h/2, h/6, h/3 | s4
 constexpr int kScanPadFront = 136; // zero records before step 0 (>= the steps of a superblock + 1: 16 x 4 in
                                    // k_backward_scan, 8 x 4 x 4 in k_backward_fcs)
 constexpr int kScanPadBack = 8;    // and after step N-1 (a wave copies 8 records per chunk)
+#ifndef OCS_SCAN_XRC
+#define OCS_SCAN_XRC 0
+#endif
+constexpr bool kScanXRC = OCS_SCAN_XRC != 0;   // checkpoints of a chunk's upper steps recomputed instead of read (k_backward_scan)
 
 // W waves per workgroup (chunks per superblock), L steps per chunk
 // ABL (diagnostic builds, -DOCS_SCAN_ABL): 1 no stores, 2 no phase 3, 3 no phase 1, 4 no loads, 5 no barrier/phase 2
@@ -197,7 +201,7 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
     const int lr = lo >= 0 ? lo - 1 : -kScanPadFront;
     if (q == 0) dma16_sc(a.RECS + (long long)lr * kScanRec + 2 * lane, &rcs[slot][wave][0]);
     const Buf bx = Buf::make(a.xck + (size_t)lc * colB, ABL == 4 ? 0 : kNumRec), bu = Buf::make(a.u + (size_t)(2 * lc) * B, ABL == 4 ? 0 : kNumRec);
-    d.x[q] = bx.ld(vx, (unsigned)q * col8);
+    if (!kScanXRC || q == 0) d.x[q] = bx.ld(vx, (unsigned)q * col8);
     d.u[2 * q] = bu.ld(vu, (unsigned)(2 * q) * B8);
     d.u[2 * q + 1] = bu.ld(vu, (unsigned)(2 * q + 1) * B8);
     if (q == L - 1) d.u[2 * L] = bu.ld(vu, (unsigned)(2 * L) * B8);
@@ -231,12 +235,30 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
     else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     const double* rw = &rcs[slot][wave][0];
+    // (kScanXRC) only the checkpoint of the chunk's first step was read: the other L - 1 are integrated again from it,
+    // RK4Integrator.m:37-50 on this row -- 8 (nS) bytes per (trajectory, step) instead of 8 nS of checkpoint traffic
+    double xs[L];
+    xs[0] = d.x[0];
+#pragma unroll
+    for (int q = 0; q + 1 < L; ++q) {
+      if (kScanXRC) {
+        const Rc c = rec_of(rw, q);
+        const double xi = xs[q], uA = d.u[2 * q], uM = d.u[2 * q + 1], uB = d.u[2 * q + 2];
+        const double F1 = P::g_row_f(xi, uA, c.tA, rp);
+        const double F2 = P::g_row_f(__builtin_fma(c.hh, F1, xi), uM, c.tM, rp);
+        const double F3 = P::g_row_f(__builtin_fma(c.hh, F2, xi), uM, c.tM, rp);
+        const double F4 = P::g_row_f(__builtin_fma(c.h, F3, xi), uB, c.tB, rp);
+        xs[q + 1] = __builtin_fma(c.h6, ((F1 + 2.0 * F2) + 2.0 * F3) + F4, xi);   // :50
+      } else {
+        xs[q + 1] = d.x[q + 1];
+      }
+    }
     // ---------------- phase 1: stage states and the chunk map ----------------
     double A = 1.0, Bq = 0.0;
 #pragma unroll
     for (int q = L - 1; q >= 0 && ABL != 3; --q) {
       const Rc c = rec_of(rw, q);
-      const double xi = d.x[q], uA = d.u[2 * q], uM = d.u[2 * q + 1], uB = d.u[2 * q + 2];
+      const double xi = xs[q], uA = d.u[2 * q], uM = d.u[2 * q + 1], uB = d.u[2 * q + 2];
       double f = P::g_row_f(xi, uA, c.tA, rp);                 // compute_states :39-46, this row
       const double Y2 = __builtin_fma(c.hh, f, xi);
       f = P::g_row_f(Y2, uM, c.tM, rp);
@@ -298,12 +320,12 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
       for (int q0 = 0; q0 < L; q0 += G) bl.st(lamc, vc, (unsigned)q0 * col8);
     }
     double pend = topc ? pend_top : 0.0;   // this row's B'k1 share of the node above
-    if (ABL == 2) lam += d.x[0] + d.u[0];
+    if (ABL == 2) lam += xs[0] + d.u[0];
 #pragma unroll
     for (int q = L - 1; q >= 0 && ABL != 2; --q) {
       const Rc c = rec_of(rw, q);
       // the stage states again (held registers are worth more than these nine operations: 4 waves per SIMD)
-      const double xi = d.x[q], uA = d.u[2 * q], uM = d.u[2 * q + 1], uB = d.u[2 * q + 2];
+      const double xi = xs[q], uA = d.u[2 * q], uM = d.u[2 * q + 1], uB = d.u[2 * q + 2];
       double f = P::g_row_f(xi, uA, c.tA, rp);
       const double Y2 = __builtin_fma(c.hh, f, xi);
       f = P::g_row_f(Y2, uM, c.tM, rp);

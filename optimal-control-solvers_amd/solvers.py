@@ -95,6 +95,36 @@ def single_shooting(prob, x0, tspan, nCONTROL_PTS, **kw):
             Lb, Ub = np.concatenate([Lb, fsb[:, 0]]), np.concatenate([Ub, fsb[:, 1]])
         bounds = list(zip(Lb, Ub))
 
+    nV0 = v0.size - nFREE
+    cons = []
+    if hasattr(control, "compute_nonlcon"):                                      # :99-104  [c, ceq(, gradc, gradceq)] = nonlcon(v)
+        def _nl(v, k):
+            out = control.compute_nonlcon(v[:nV0])
+            val = np.atleast_1d(np.asarray(out[k], dtype=np.float64)).ravel()
+            return -val if k == 0 else val                                       # fmincon: c(v) <= 0; SLSQP: fun(v) >= 0
+
+        def _nlj(v, k):
+            out = control.compute_nonlcon(v[:nV0])
+            if len(out) < 4:
+                return None
+            G = np.atleast_2d(np.asarray(out[2 + k], dtype=np.float64))          # GradConstr 'on' (:101): columns = gradients
+            G = G.reshape(nV0, -1).T
+            G = np.hstack([G, np.zeros((G.shape[0], nFREE))])
+            return -G if k == 0 else G
+        probe = control.compute_nonlcon(v0[:nV0])
+        for k, kind in ((0, "ineq"), (1, "eq")):
+            if np.size(probe[k]):
+                c = {"type": kind, "fun": (lambda v, k=k: _nl(v, k))}
+                if len(probe) >= 4:
+                    c["jac"] = (lambda v, k=k: _nlj(v, k))
+                cons.append(c)
+    if hasattr(control, "compute_lincon"):                                       # :106-111  A v <= b
+        A, b = control.compute_lincon(prob.ControlBounds)
+        A, b = np.atleast_2d(np.asarray(A, dtype=np.float64)), np.asarray(b, dtype=np.float64).ravel()
+        if A.size:
+            Af = np.hstack([A, np.zeros((A.shape[0], nFREE))])
+            cons.append({"type": "ineq", "fun": (lambda v: b - Af @ v), "jac": (lambda v: -Af)})
+
     hist = []
 
     def fun(v):                                                                  # nlpObjective :137-150
@@ -102,7 +132,20 @@ def single_shooting(prob, x0, tspan, nCONTROL_PTS, **kw):
         hist.append(J)
         return J, dJdv
 
-    res = minimize(fun, v0, jac=True, method="SLSQP", bounds=bounds,
+    # TolX (:20, fmincon's step tolerance): SLSQP has no such option -- the iteration is ended from the callback when
+    # an iterate moved by less than TolX in every coefficient.  TolFun (:21) goes to SLSQP's ftol, the tolerance on the
+    # change of the objective (fmincon's is a first-order optimality measure): 1e-3 of it, as before, because SLSQP's
+    # test is relative to nothing and 3e-4 of an O(10) objective stops it far from the KKT point.
+    last = {"v": np.array(v0, dtype=np.float64), "stopped": False}
+
+    def cb(vk):
+        step = float(np.max(np.abs(vk - last["v"]))) if vk.size else 0.0
+        last["v"] = np.array(vk, dtype=np.float64)
+        if opt["TolX"] and 0.0 < step < opt["TolX"]:
+            last["stopped"] = True
+            raise StopIteration
+
+    res = minimize(fun, v0, jac=True, method="SLSQP", bounds=bounds, constraints=cons, callback=cb,
                    options={"ftol": opt["TolFun"] * 1e-3, "maxiter": opt["MaxIter"], "disp": bool(opt["Reporting"])})
     vOpt = res.x
     soln = {"J": -res.fun if MinMax == "Max" else res.fun}                       # :117-119
@@ -116,6 +159,7 @@ def single_shooting(prob, x0, tspan, nCONTROL_PTS, **kw):
     soln["x"] = vectorInterpolant(tspan, xOpt[:-1, :], "pchip")                  # :129
     soln["lam"] = vectorInterpolant(tspan, lamOpt[:-1, :], "pchip")              # :130
     soln["_v"], soln["_nfev"], soln["_message"] = vOpt, res.nfev, res.message
+    soln["_stopped_on_TolX"], soln["_constraints"] = last["stopped"], len(cons)
     return soln
 
 
@@ -167,7 +211,8 @@ def compute_equilibrium_dev(prob, yGuess, lb, ub, r):
 
 
 def single_shooting_batch(prob, x0, tspan, nCONTROL_PTS, Control=None, Integrator=None, u0=0.0, TolX=1e-5,
-                          TolFun=3e-4, MaxIter=500, memory=10, FreeInitStates=(), FreeStateBounds=None, v0=None):
+                          TolFun=3e-4, MaxIter=500, memory=10, FreeInitStates=(), FreeStateBounds=None, v0=None,
+                          constraints="warn"):
     """Batched direct single shooting: B independent NLPs  min_v J_b(v), Lb <= v <= Ub  --
     one per column of x0 and/or per per-trajectory parameter set of `prob` -- solved together on the GPU by the
     library's ocs_single_shooting_batch_dev.
@@ -204,6 +249,16 @@ def single_shooting_batch(prob, x0, tspan, nCONTROL_PTS, Control=None, Integrato
         Lb, Ub = control.compute_nlp_bounds(prob.ControlBounds)
     else:
         Lb, Ub = np.full(nV, -np.inf), np.full(nV, np.inf)
+    # The projected gradient iteration projects on a BOX: the constraint hooks of single_shooting.m:99-111
+    # (compute_nonlcon, compute_lincon) have no counterpart here.  A control that defines them (ChebyshevControl's bounds
+    # at the grid points) is iterated without them -- said once, not silently; single_shooting() honours them.
+    if constraints == "error" and (hasattr(control, "compute_lincon") or hasattr(control, "compute_nonlcon")):
+        raise ValueError("single_shooting_batch takes box bounds (compute_nlp_bounds) only; this control defines "
+                         "compute_lincon / compute_nonlcon -- use single_shooting, or pass constraints='ignore'")
+    if constraints == "warn" and (hasattr(control, "compute_lincon") or hasattr(control, "compute_nonlcon")):
+        import warnings
+        warnings.warn("single_shooting_batch: compute_lincon / compute_nonlcon of the control are not applied (box bounds "
+                      "only); single_shooting honours them", RuntimeWarning, stacklevel=2)
     if nFree:                                                             # :84: v0 = [v0; x0(FreeInitStates)]
         idx = [int(i) - 1 for i in np.asarray(FreeInitStates).ravel()]
         v0 = np.vstack([v0, x0[idx, :]])

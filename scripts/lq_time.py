@@ -13,6 +13,8 @@ Bu = rng.normal(size=(nS, nC))
 q, rd = rng.uniform(0.5, 1.5, nS), rng.uniform(1, 2, nC)
 prob = ocs.LQProblem(A, Bu, q, rd, 0.05, [[-1.0, 1.0]] * nC)
 integ = ocs.RK4InfiniteIntegrator(np.linspace(0, T, N + 1), np.linspace(T, 2 * T, N + 1), np.zeros(nC))
+if os.environ.get("MAPPING"):   # 1 one wave / 2 two / 3 four waves per 16 trajectories, 4 time-parallel chunks
+    integ.set_mapping(int(os.environ["MAPPING"]))
 gen = torch.Generator(device=dev).manual_seed(20260405)
 u = torch.rand((2 * N + 1, nC, batch), dtype=torch.float64, device=dev, generator=gen) * 2 - 1
 x0 = torch.randn((nS, batch), dtype=torch.float64, device=dev, generator=gen)
@@ -24,7 +26,7 @@ torch.cuda.synchronize()
 ev = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
 fl_bwd = 7 * 2 * nS * nS + 2 * 2 * nS * nC + 2 * 2 * nS * nC
 fl_fwd = 4 * 2 * nS * nS + 3 * 2 * nS * nC
-for rep in range(3):
+for rep in range(int(os.environ.get("REPS", "3"))):
     ev[0].record(); integ.compute_states_dev(prob, x0, u, x, J)
     ev[1].record(); integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
     ev[2].record(); torch.cuda.synchronize()

@@ -169,6 +169,62 @@ def test_single_shooting_end_to_end(ocs, oracle):
     assert soln["x"](np.array([0.0]))[0, 0] == 1.0 and soln["lam"](tq).shape == (1, 3)
 
 
+def test_single_shooting_constraint_hooks_and_tolx(ocs, oracle):
+    """single_shooting.m:99-115: compute_lincon / compute_nonlcon of the control object reach the optimiser, TolX ends
+    the iteration.  ChebyshevControl has no bounds of its own (its compute_lincon is empty in the reference,
+    ChebyshevControl.m:51-53); with the linear constraints at the grid points the optimal control of the test problem --
+    which without them sits on the turnpike u* = 0.72 above the upper bound 0.5 -- stays inside ControlBounds."""
+    tspan = oracle.linspace(0, 10, 201)
+    prob = ocs.TestOCProblem(P, [[0.0, 0.5]])
+    integ = ocs.RK4Integrator(tspan)
+
+    free_c = ocs.ChebyshevControl(integ.t, 12, 1)
+    s_con = ocs.single_shooting(prob, [2.9], tspan, 12, u0=0.4, Control=free_c, Integrator=integ, TolX=0)
+    A, b = free_c.compute_lincon(prob.ControlBounds)
+    assert A.shape == (2 * integ.t.size, 12) and s_con["_constraints"] == 1
+    assert np.all(A @ s_con["_v"] <= b + 1e-7)
+    tq = integ.t
+    ucon = s_con["u"](tq)
+    assert ucon.max() <= 0.5 + 1e-6 and ucon.min() >= -1e-6
+    s_unc = ocs.single_shooting(prob, [2.9], tspan, 12, u0=0.4, Control=_NoLincon(ocs, integ.t, 12, 1), Integrator=integ, TolX=0)
+    assert s_unc["_constraints"] == 0 and s_unc["u"](tq).max() > 0.5 + 1e-3 and s_unc["J"] < s_con["J"]
+    # a nonlinear constraint with its gradient (GradConstr 'on', :101): the mean square of the coefficients above the first
+    nl = _NonlconControl(ocs, integ.t, 12, 1, 1e-3)
+    s_nl = ocs.single_shooting(prob, [2.9], tspan, 12, u0=0.4, Control=nl, Integrator=integ, TolX=0)
+    assert s_nl["_constraints"] == 1 and np.sum(s_nl["_v"][1:] ** 2) <= 1e-3 * (1 + 1e-6) < np.sum(s_unc["_v"][1:] ** 2)
+    # TolX: a loose step tolerance ends the iteration early (fewer evaluations, objective within first order of the step)
+    s_tx = ocs.single_shooting(prob, [2.9], tspan, 12, u0=0.4, Control=_NoLincon(ocs, integ.t, 12, 1), Integrator=integ, TolX=1e-2)
+    assert s_tx["_stopped_on_TolX"] and s_tx["_nfev"] < s_unc["_nfev"] and s_tx["J"] >= s_unc["J"] - 1e-9
+    # the batched projected-gradient driver takes box bounds only and says so
+    with pytest.warns(RuntimeWarning):
+        ocs.single_shooting_batch(prob, np.full((1, 4), 2.9), tspan, 12, Control=free_c, Integrator=integ, u0=0.5, MaxIter=3)
+    with pytest.raises(ValueError):
+        ocs.single_shooting_batch(prob, np.full((1, 4), 2.9), tspan, 12, Control=free_c, Integrator=integ, constraints="error")
+
+
+def _NoLincon(ocs, *a):
+    class C(ocs.ChebyshevControl):
+        def __getattribute__(self, name):   # the reference's ChebyshevControl as shipped: no usable constraint hook
+            if name == "compute_lincon":
+                raise AttributeError(name)
+            return super().__getattribute__(name)
+    return C(*a)
+
+
+def _NonlconControl(ocs, t, nB, nC, cap):
+    class C(ocs.ChebyshevControl):
+        def __getattribute__(self, name):
+            if name == "compute_lincon":
+                raise AttributeError(name)
+            return super().__getattribute__(name)
+
+        def compute_nonlcon(self, v):       # [c, ceq, gradc, gradceq] = compute_nonlcon(obj, v)   Control.m:12
+            g = 2 * v
+            g[0] = 0.0
+            return np.array([np.sum(v[1:] ** 2) - cap]), np.zeros(0), g[:, None], np.zeros((v.size, 0))
+    return C(t, nB, nC)
+
+
 def test_compute_equilibrium_and_solve_test_problem_script(ocs, oracle):
     """tests/solve_test_problem.m:21-39 end to end: equilibrium (analytic KAT 1) -> RK4InfiniteIntegrator with
     uStar -> single_shooting with that integrator (the line the reference leaves commented out, :38-39)."""

@@ -43,7 +43,7 @@ def test_plugin_methods(ocs, oracle, nS, nC):
     assert relerr(pg.dFdu_times_vec(t, y, u, v), po.dFdu_times_vec(t, y, u, v)) < 1e-13
 
 
-@pytest.mark.parametrize("mapping", [0, 1, 2, 3])
+@pytest.mark.parametrize("mapping", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("nS,nC,N,batch", [(1, 1, 7, 3), (5, 2, 33, 37), (16, 4, 64, 16), (17, 2, 20, 19), (20, 3, 50, 50),
                                            (32, 4, 96, 68), (32, 1, 3, 1)])
 def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch, mapping):
@@ -54,7 +54,7 @@ def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch, mapping):
     x0 = rng.normal(size=(nS, batch))
     lamT = rng.normal(size=(nS + 1, batch))
     g, go = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
-    g.set_mapping(mapping)   # 0: automatic (two waves per 16 trajectories when nS > 16), 1: one wave
+    g.set_mapping(mapping)   # 0: automatic, 1: one wave per 16 trajectories, 2: two, 3: four, 4: time-parallel chunks
     x, J = g.compute_states(pg, x0, u)
     lam, dJdu = g.compute_adjoints(pg, u)
     for b in sorted({0, batch // 2, batch - 1}):
@@ -72,7 +72,7 @@ def test_states_adjoints_vs_oracle(ocs, oracle, nS, nC, N, batch, mapping):
         assert relerr(lam2[:, :, b], lamo) < RTOL and relerr(d2[:, :, b], do) < RTOL
 
 
-@pytest.mark.parametrize("mapping", [0, 1, 2, 3])
+@pytest.mark.parametrize("mapping", [0, 1, 2, 3, 4])
 def test_infinite_horizon_and_shooting_objective(ocs, oracle, mapping):
     """BL-5 shape at reduced size: nS = 32, nC = 4, RK4InfiniteIntegrator with uStar = 0, then the shooting objective
     (single_shooting.m:137-150) through a PWLinear basis with nC = 4 and a free initial state."""
@@ -99,6 +99,57 @@ def test_infinite_horizon_and_shooting_objective(ocs, oracle, mapping):
     for b in range(5):
         Jo, do, _ = oracle.nlp_objective(go, po, co, x0[:, b], V[:, b], free)
         assert abs(Jn[b] - Jo) < RTOL * max(1, abs(Jo)) and relerr(dJdv[:, b], do) < RTOL
+
+
+@pytest.mark.parametrize("nS,nC,N,N2,batch", [(32, 4, 517, 300, 40), (12, 2, 256, 130, 100)])
+def test_time_parallel_chunks_selected_automatically(ocs, oracle, nS, nC, N, N2, batch):
+    """A small batch on a long horizon runs the chunked passes without being asked (csrc/ocs_lq_kernels.hip, "chunked
+    passes": 8 - 16 chunks here, the last one ragged, non-uniform grid): RK4InfiniteIntegrator against the oracle, and
+    against the serial one-wave mapping -- equal to round-off but not bit for bit (other kernels ran), J == x(end,end)
+    of the leg-1 sum as in every mapping, lam(end,:) == 1, lam-only / dJdu-only / J-only calls."""
+    pg, po = make(ocs, oracle, nS, nC)
+    rng = np.random.default_rng(N)
+    tspan = np.concatenate([[0.0], np.sort(rng.uniform(0.0, 2.0, N - 1)), [2.0]])
+    tx = oracle.linspace(2, 3, N2 + 1)
+    u = rng.uniform(-1, 1, (nC, 2 * N + 1, batch))
+    x0 = rng.normal(size=(nS, batch))
+    ustar = rng.uniform(-0.3, 0.3, nC)
+    gi, gs, go = (ocs.RK4InfiniteIntegrator(tspan, tx, ustar), ocs.RK4InfiniteIntegrator(tspan, tx, ustar).set_mapping(1),
+                  oracle.RK4InfiniteIntegrator(tspan, tx, ustar))
+    x, J = gi.compute_states(pg, x0, u)
+    lam, dJdu = gi.compute_adjoints(pg, u)
+    xs, Js = gs.compute_states(pg, x0, u)
+    lams, ds = gs.compute_adjoints(pg, u)
+    assert relerr(x, xs) < RTOL and relerr(J, Js) < RTOL and relerr(lam, lams) < RTOL and relerr(dJdu, ds) < RTOL
+    assert not np.array_equal(x, xs)   # the chunked kernels ran, not the serial ones
+    assert np.all(lam[-1] == 1.0) and np.all(np.isfinite(dJdu))
+    for b in (0, batch // 2, batch - 1):
+        xo, Jo = go.compute_states(po, x0[:, b], u[:, :, b])
+        lamo, do = go.compute_adjoints(po, u[:, :, b])
+        assert relerr(x[:, :, b], xo) < RTOL and abs(J[b] - Jo) < RTOL * max(1, abs(Jo))
+        assert relerr(lam[:, :, b], lamo) < RTOL and relerr(dJdu[:, :, b], do) < RTOL
+    # plain RK4Integrator, explicit lamT, partial outputs
+    g1, go1 = ocs.RK4Integrator(tspan), oracle.RK4Integrator(tspan)
+    lamT = rng.normal(size=(nS + 1, batch))
+    x1, J1 = g1.compute_states(pg, x0, u)
+    assert np.array_equal(J1, x1[-1, -1, :])
+    l1, d1 = g1.compute_adjoints(pg, u, lamT)
+    go1.compute_states(po, x0[:, 1], u[:, :, 1])
+    lamo, do = go1.compute_adjoints(po, u[:, :, 1], lamT[:, 1])
+    assert relerr(l1[:, :, 1], lamo) < RTOL and relerr(d1[:, :, 1], do) < RTOL
+    l0, d0 = g1.compute_adjoints(pg, u)
+    import torch
+    dev = torch.device("cuda:0")
+    ud = torch.tensor(np.ascontiguousarray(u.transpose(1, 0, 2)), device=dev)
+    x0d = torch.tensor(x0, device=dev)
+    _, Jd = g1.compute_states_dev(pg, x0d, ud)           # J only (checkpoints in the handle)
+    dd = torch.empty_like(ud)
+    g1.compute_adjoints_dev(pg, ud, None, None, dd)      # dJdu only
+    ld = torch.empty((N + 1, nS + 1, batch), dtype=torch.float64, device=dev)
+    g1.compute_adjoints_dev(pg, ud, None, ld, None)      # lam only
+    torch.cuda.synchronize()
+    assert relerr(Jd.cpu().numpy(), J1) < RTOL
+    assert relerr(dd.cpu().numpy().transpose(1, 0, 2), d0) < RTOL and relerr(ld.cpu().numpy().transpose(1, 0, 2), l0) < RTOL
 
 
 def test_matches_user_plugin_path(ocs):
@@ -157,8 +208,10 @@ def test_unsupported_shapes_fail_loudly(ocs):
         ocs.LQProblem(A, Bu, q, rdiag, 0.05, [[-1, 1]] * 5)   # nC > 4
 
 
-def test_bl5_full_size_properties(ocs):
-    """BASELINE config 5 at full size (nS = 32, nC = 4, N = 4000 + 4000 tail steps, batch 8192) through properties
+@pytest.mark.parametrize("batch", [8192, 1024])
+def test_bl5_full_size_properties(ocs, batch):
+    """BASELINE config 5 at full size (nS = 32, nC = 4, N = 4000 + 4000 tail steps, batch 8192; and its 8-GPU shard of
+    1024 trajectories, which runs the time-parallel chunked passes) through properties
     that need no oracle: the state rows are linear in (x0, u); J is quadratic in u, so a central difference of J
     along a direction d equals <dJdu, d> exactly (up to round-off) -- which ties the adjoint pass, the tail leg's
     lamT hand-off (RK4InfiniteIntegrator.m:27-30) and compute_dJdu to the forward pass."""
@@ -170,7 +223,7 @@ def test_bl5_full_size_properties(ocs):
     Bu = rng.normal(size=(nS, nC))
     prob = ocs.LQProblem(A, Bu, rng.uniform(0.5, 1.5, nS), rng.uniform(1, 2, nC), 0.05, [[-1.0, 1.0]] * nC)
     gi = ocs.RK4InfiniteIntegrator(np.linspace(0, T, N + 1), np.linspace(T, 2 * T, N + 1), np.zeros(nC))
-    third, batch = 2730, 8192
+    third = batch // 3
     gen = torch.Generator(device=dev).manual_seed(7)
     ua = torch.rand((2 * N + 1, nC, third), dtype=torch.float64, device=dev, generator=gen) * 2 - 1
     d = torch.rand((2 * N + 1, nC, third), dtype=torch.float64, device=dev, generator=gen) * 2 - 1
@@ -205,7 +258,7 @@ def test_bl5_full_size_properties(ocs):
     assert bool((x[:, :, 3 * third:] == x[:, :, :pad]).all()) and bool((dJdu[:, :, 3 * third:] == dJdu[:, :, :pad]).all())
 
 
-@pytest.mark.parametrize("mapping", [0, 1, 2, 3])
+@pytest.mark.parametrize("mapping", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("nS", [7, 32])
 def test_known_answer_decoupled_linear_system(ocs, mapping, nS):
     """A known answer that owes nothing to the oracle: for x' = diag(lambda) x + Bu u with constant u and q = 0 the RK4

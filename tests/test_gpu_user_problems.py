@@ -424,3 +424,97 @@ def test_fb_sweep_full_vector_plugin_on_the_vector_mappings(ocs, oracle, N, batc
         so = oracle.fb_sweep(po, x0[:, b], tspan, opts)
         assert su["sweeps"][b] == so["_sweeps"] and abs(su["J"][b] - so["J"]) < 1e-10 * abs(so["J"])
         assert relerr(su["lam"][:, :, b], so["lam"]) < 1e-10 and relerr(su["u"][:, :, b], so["u"]) < 1e-10
+
+
+# ---- plugins generated from symbols (optimal-control-solvers_amd/symbolic.py; functions/make_from_symbolic.m) ----------
+def _sym_logistic(ocs, nS):
+    import importlib
+
+    import sympy as sp
+    sym = importlib.import_module("ocs_amd.symbolic")
+    names = ["c", "r"] + [f"m{k + 1}" for k in range(nS)]
+    t, x, lam, u, p = sym.symbols(nS, 1, names)
+    g = sp.exp(-p["r"] * t) * (sum(xi ** 2 for xi in x) + p["c"] * u[0] ** 2)
+    f = [x[k] * (p[f"m{k + 1}"] - x[k]) - u[0] for k in range(nS)]
+    vals = {"c": 1.5, "r": 0.05, **{f"m{k + 1}": [3.0, 2.5, 2.0, 1.5][k] for k in range(nS)}}
+    return g, f, vals
+
+
+@pytest.mark.parametrize("nS,rows", [(1, True), (2, True), (4, True), (2, False)])
+def test_problem_generated_from_symbols_equals_registry_problem(ocs, oracle, nS, rows):
+    """TestOCProblem / LogisticK from their two symbolic expressions (make_from_symbolic.m:1-38): the generated plugin
+    -- as row functions with the costate-only declaration, and kept as full-vector methods -- against the registry
+    problem to 1e-14 on the integrator passes, and through fb_sweep (the generated ControlChar with the clamp of :111)
+    with the oracle's sweep counts; the row form runs the two-kernel sweep."""
+    g, f, vals = _sym_logistic(ocs, nS)
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    ps = ocs.make_from_symbolic(g, f, nS, 1, vals, BOUNDS, allow_rows=rows)
+    assert ps.generated["form"] == ("rows" if rows else "vector") and ps.generated["has_control_char"]
+    pb, po = ocs.LogisticProblem(m, 1.5, 0.05, BOUNDS), oracle.LogisticProblem(m, 1.5, 0.05, BOUNDS)
+    rng = np.random.default_rng(nS)
+    k = 9
+    t, y = rng.uniform(0, 10, k), rng.normal(1.5, 0.5, (nS + 1, k))
+    u, v = rng.uniform(0, 1, (1, k)), rng.normal(size=(nS + 1, k))
+    assert relerr(ps.F(t, y, u), po.F(t, y, u)) < 1e-14
+    assert relerr(ps.dFdx_times_vec(t, y, u, v), po.dFdx_times_vec(t, y, u, v)) < 1e-14
+    assert relerr(ps.dFdu_times_vec(t, y, u, v), po.dFdu_times_vec(t, y, u, v)) < 1e-14
+    N, batch = 200, 128
+    tspan = oracle.linspace(0, 10, N + 1)
+    uu, x0 = rng.uniform(0.05, 0.45, (1, 2 * N + 1, batch)), rng.uniform(0.9, 2.0, (nS, batch))
+    gs, gb = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
+    xs, Js = gs.compute_states(ps, x0, uu)
+    ls, ds = gs.compute_adjoints(ps, uu)
+    xb, Jb = gb.compute_states(pb, x0, uu)
+    lb, db = gb.compute_adjoints(pb, uu)
+    assert relerr(xs, xb) < 1e-13 and relerr(Js, Jb) < 1e-13 and relerr(ls, lb) < 1e-13 and relerr(ds, db) < 1e-13
+    ts = oracle.linspace(0, 8, 161)
+    opt = {"nERROR_PTS": 161, "nINTERP_PTS": 81}
+    X0 = rng.uniform(0.9, 2.0, (nS, 64))
+    s1 = ocs.fb_sweep_batch(ps, X0, ts, opt, integrator=(gi := ocs.RK4Integrator(ts)))
+    s2 = ocs.fb_sweep_batch(pb, X0, ts, opt)
+    ok = s1["sweeps"] > 0   # (with four states the undamped sweep of fb_sweep.m:79-87 does not converge: on every path alike)
+    assert np.array_equal(s1["sweeps"], s2["sweeps"]) and (nS == 4 or ok.all())
+    for k in ("J", "u", "lam"):
+        assert not ok.any() or relerr(s1[k][..., ok], s2[k][..., ok]) < 1e-10
+    so = oracle.fb_sweep(po, X0[:, 3], ts, opt)
+    assert s1["sweeps"][3] == max(so["_sweeps"], 0) and (not ok[3] or abs(s1["J"][3] - so["J"]) < 1e-10 * abs(so["J"]))
+    if rows:
+        assert ocs.fb_sweep_path(gi) == 4   # row functions + ControlChar of the costate alone: the two-kernel sweep
+
+
+def test_predator_prey_generated_from_symbols_equals_hand_written_plugin(ocs, oracle):
+    import importlib
+
+    import sympy as sp
+    sym = importlib.import_module("ocs_amd.symbolic")
+    names = ["al", "be", "de", "ga", "c", "q", "xb", "r"]
+    t, x, lam, u, p = sym.symbols(2, 1, names)
+    g = sp.exp(-p["r"] * t) * (p["c"] * u[0] ** 2 + p["q"] * (x[0] - p["xb"]) ** 2)
+    f = [x[0] * (p["al"] - p["be"] * x[1]), x[1] * (p["de"] * x[0] - p["ga"]) - u[0] * x[1]]
+    ps = ocs.make_from_symbolic(g, f, 2, 1, dict(zip(names, PREDPREY_PARAMS)), BOUNDS)
+    ph = ocs.UserProblem(PREDPREY_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS)
+    assert ps.generated["form"] == "vector" and ps.generated["tcoef"] is not None
+    rng = np.random.default_rng(3)
+    N, batch = 120, 128
+    tspan = oracle.linspace(0, 6, N + 1)
+    uu, x0 = rng.uniform(0.0, 0.6, (1, 2 * N + 1, batch)), rng.uniform(0.8, 1.6, (2, batch))
+    gs, gh = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
+    xs, Js = gs.compute_states(ps, x0, uu)
+    ls, ds = gs.compute_adjoints(ps, uu)
+    xh, Jh = gh.compute_states(ph, x0, uu)
+    lh, dh = gh.compute_adjoints(ph, uu)
+    assert relerr(xs, xh) < 1e-13 and relerr(Js, Jh) < 1e-13 and relerr(ls, lh) < 1e-13 and relerr(ds, dh) < 1e-13
+    # and against the NumPy twin of the hand-written plugin on one trajectory
+    tw_i = tw.RK4IntegratorNP(tspan)
+    xo, Jo = tw_i.compute_states(PredPreyNP(), x0[:, 5], uu[:, :, 5])
+    assert relerr(xs[:, :, 5], xo) < RTOL and abs(Js[5] - Jo) < RTOL * max(1, abs(Jo))
+    # fb_sweep: the generated ControlChar (reads x: kernel-by-kernel / vector sweep) converges to a control that satisfies
+    # its own definition
+    ts = oracle.linspace(0, 4, 201)
+    r = ocs.fb_sweep_batch(ps, rng.uniform(0.8, 1.6, (2, 64)), ts, {"nERROR_PTS": 201, "nINTERP_PTS": 201, "nSWEEPS": 100})
+    ok = r["sweeps"] > 0
+    assert ok.any()
+    g1 = ps.gen1
+    b = int(np.flatnonzero(ok)[0])
+    uc = g1.ControlChar(ts, r["x"][:, :, b], r["lam"][:, :, b])
+    assert relerr(uc, r["u"][:, :, b]) < 1e-9

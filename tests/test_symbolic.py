@@ -1,0 +1,116 @@
+"""The symbolic front-end (optimal-control-solvers_amd/symbolic.py; reference functions/make_from_symbolic.m:11-38,102-112):
+the derivation H = g + lam f, adjointRHS = -grad_x H, dHdu, ControlChar = solve(dHdu = 0) with the clamp, against the
+hand-derived expressions of the test problems; the plugin form the generator picks; and that every generated source
+compiles for gfx950 (hipRTC, no GPU needed).  The GPU half (generated plugin == hand-written plugin == registry problem
+on the device) is in tests/test_gpu_user_problems.py."""
+import importlib
+
+import numpy as np
+import pytest
+import sympy as sp
+
+from tests.user_problems import PREDPREY_PARAMS, PredPreyNP
+
+
+@pytest.fixture(scope="module")
+def ocs():
+    import __graft_entry__ as g
+    return g.load_package()
+
+
+@pytest.fixture(scope="module")
+def sym(ocs):
+    return importlib.import_module("ocs_amd.symbolic")
+
+
+def logistic(sym, nS):
+    names = ["c", "r"] + [f"m{k + 1}" for k in range(nS)]
+    t, x, lam, u, p = sym.symbols(nS, 1, names)
+    g = sp.exp(-p["r"] * t) * (sum(xi ** 2 for xi in x) + p["c"] * u[0] ** 2)
+    f = [x[k] * (p[f"m{k + 1}"] - x[k]) - u[0] for k in range(nS)]
+    vals = {"c": 1.5, "r": 0.05, **{f"m{k + 1}": [3.0, 2.5, 2.0, 1.5][k] for k in range(nS)}}
+    return g, f, vals
+
+
+def predprey(sym):
+    names = ["al", "be", "de", "ga", "c", "q", "xb", "r"]
+    t, x, lam, u, p = sym.symbols(2, 1, names)
+    g = sp.exp(-p["r"] * t) * (p["c"] * u[0] ** 2 + p["q"] * (x[0] - p["xb"]) ** 2)
+    f = [x[0] * (p["al"] - p["be"] * x[1]), x[1] * (p["de"] * x[0] - p["ga"]) - u[0] * x[1]]
+    return g, f, dict(zip(names, PREDPREY_PARAMS))
+
+
+def test_test_oc_problem_from_symbols(ocs, sym):
+    """tests/TestOCProblem.m:22-38 from its two expressions: row functions, ControlChar of the costate alone
+    (u* = lam e^{rt} / (2c)), both time coefficients hoisted."""
+    g, f, vals = logistic(sym, 1)
+    gen = sym.generate(g, f, 1, 1, vals, [[0.0, 1.0]])
+    t, x, lam, u, p = sym.symbols(1, 1, list(vals))
+    assert gen["form"] == "rows" and gen["row_separable"] and gen["has_control_char"] and gen["control_from_costate"]
+    assert sp.simplify(gen["tcoef"] - sp.exp(-p["r"] * t)) == 0 and sp.simplify(gen["cc_tcoef"] - sp.exp(p["r"] * t)) == 0
+    assert sp.simplify(gen["ControlChar"][0] - lam[0] * sp.exp(p["r"] * t) / (2 * p["c"])) == 0
+    assert sp.simplify(gen["adjointRHS"][0] + (2 * x[0] * sp.exp(-p["r"] * t) + lam[0] * (p["m1"] - 2 * x[0]))) == 0
+    ocs.UserProblem.check_source(gen["source"], 1, 1, 3, True, True, True)
+    # the Gen-1 handles (make_from_symbolic.m:33-38) as NumPy callables, with the clamp of :111
+    g1 = sym.Gen1Functions(gen)
+    tt, xx, ll = np.array([0.0, 2.0, 5.0]), np.array([[1.0, 2.0, 2.5]]), np.array([[0.5, 4.0, -1.0]])
+    assert np.allclose(g1.ControlChar(tt, xx, ll), np.clip(ll * np.exp(0.05 * tt) / 3.0, 0.0, 1.0), rtol=0, atol=1e-15)
+    uu = np.array([[0.2, 0.4, 0.9]])
+    assert np.allclose(g1.stateRHS(tt, xx, uu), xx * (3.0 - xx) - uu)
+    assert np.allclose(g1.objective(tt, xx, uu), np.exp(-0.05 * tt) * (xx ** 2 + 1.5 * uu ** 2))
+    assert np.allclose(g1.dHdu(tt, xx, ll, uu), -ll + 3.0 * np.exp(-0.05 * tt) * uu)
+
+
+@pytest.mark.parametrize("nS", [2, 4])
+def test_logistic_rows_from_symbols(ocs, sym, nS):
+    g, f, vals = logistic(sym, nS)
+    gen = sym.generate(g, f, nS, 1, vals, [[0.0, 1.0]])
+    assert gen["form"] == "rows" and gen["control_from_costate"] and "ocs_row_dFdu" in gen["source"]
+    ocs.UserProblem.check_source(gen["source"], nS, 1, len(vals), True, True, True)
+    # the same expressions kept in the full-vector form
+    gv = sym.generate(g, f, nS, 1, vals, [[0.0, 1.0]], allow_rows=False)
+    assert gv["form"] == "vector" and "OCS_USER_TCOEF" in gv["source"] and "ocs_dFdx_times_vec" in gv["source"]
+    ocs.UserProblem.check_source(gv["source"], nS, 1, len(vals), True, False, False)
+
+
+def test_predator_prey_from_symbols(ocs, sym):
+    """A coupled problem: full-vector methods, ControlChar reads x (no costate-only declaration); the derived
+    dFdx_times_vec / dFdu_times_vec agree with the hand-written NumPy twin of the plugin."""
+    g, f, vals = predprey(sym)
+    gen = sym.generate(g, f, 2, 1, vals, [[0.0, 1.0]])
+    assert gen["form"] == "vector" and gen["has_control_char"] and not gen["control_from_costate"]
+    ocs.UserProblem.check_source(gen["source"], 2, 1, 8, True, False, False)
+    g1, tw = sym.Gen1Functions(gen), PredPreyNP()
+    rng = np.random.default_rng(1)
+    k = 7
+    tt, y, uu, lam = rng.uniform(0, 5, k), rng.uniform(0.5, 2, (3, k)), rng.uniform(0, 1, (1, k)), rng.normal(size=(2, k))
+    v = np.vstack([lam, np.ones((1, k))])
+    # SURVEY A9 adapter: adjointRHS = -dFdx_times_vec(t, [x; 0], u, [lam; 1])(1:nS), dHdu = dFdu_times_vec(...)
+    assert np.allclose(g1.adjointRHS(tt, y[:2], lam, uu), -tw.dFdx_times_vec(tt, y, uu, v)[:2], rtol=1e-13, atol=1e-13)
+    assert np.allclose(g1.dHdu(tt, y[:2], lam, uu), tw.dFdu_times_vec(tt, y, uu, v), rtol=1e-13, atol=1e-13)
+    assert np.allclose(np.vstack([g1.stateRHS(tt, y[:2], uu), g1.objective(tt, y[:2], uu)]), tw.F(tt, y, uu), rtol=1e-13)
+
+
+def test_forms_the_generator_refuses_or_degrades(ocs, sym):
+    # two distinct time dependences: no tabulated coefficient, the methods read t
+    t, x, lam, u, p = sym.symbols(1, 1, ["c", "r"])
+    gen = sym.generate(sp.exp(-p["r"] * t) * (x[0] ** 2 + p["c"] * u[0] ** 2), [sp.sin(t) * x[0] - u[0]], 1, 1,
+                       {"c": 1.0, "r": 0.1}, [[0, 1]])
+    assert gen["form"] == "rows" and gen["tcoef"] == t and "return t;" in gen["source"]   # tc = t: the rows evaluate exp / sin
+    ocs.UserProblem.check_source(gen["source"], 1, 1, 2, True, True, gen["control_from_costate"])
+    gv = sym.generate(sp.exp(-p["r"] * t) * (x[0] ** 2 + p["c"] * u[0] ** 2), [sp.sin(t) * x[0] - u[0]], 1, 1,
+                      {"c": 1.0, "r": 0.1}, [[0, 1]], allow_rows=False)
+    assert gv["form"] == "vector" and gv["tcoef"] is None and "double t," in gv["source"] and "OCS_USER_TCOEF" not in gv["source"]
+    ocs.UserProblem.check_source(gv["source"], 1, 1, 2, True, False, False)
+    # a Hamiltonian that is linear in u: solve(dHdu = 0, u) has no solution -> no ControlChar, the integrator methods remain
+    gen = sym.generate(x[0] ** 2 + u[0], [-x[0] + u[0]], 1, 1, {"c": 1.0, "r": 0.1}, [[0, 1]])
+    assert not gen["has_control_char"] and gen["ControlChar"] is None and "ocs_ControlChar" not in gen["source"]
+    ocs.UserProblem.check_source(gen["source"], 1, 1, 2, False, gen["row_separable"], False)
+    # two controls, three states: full-vector form
+    t, x, lam, u, p = sym.symbols(3, 2, ["a"])
+    gen = sym.generate(x[0] ** 2 + x[1] * x[2] + u[0] ** 2 + 2 * u[1] ** 2, [x[1] - u[0], x[2] * x[0] + u[1], -p["a"] * x[2] + u[0] * u[1]],
+                       3, 2, {"a": 0.5}, [[-1, 1], [-2, 2]])
+    assert gen["form"] == "vector"
+    ocs.UserProblem.check_source(gen["source"], 3, 2, 1, gen["has_control_char"], False, False)
+    with pytest.raises(ValueError):
+        sym.generate(sp.Symbol("z") * x[0], [x[0], x[1], x[2]], 3, 2, {"a": 0.5})
