@@ -377,6 +377,14 @@ int ocs_multi_fb_sweep_dev(ocs_multi m, const ocs_integrator *g, const ocs_probl
                            double *const *uInterp, double *const *J, int *const *sweeps, double *const *maxChange,
                            int reduce);
 
+/* device buffers for hosts without a GPU array type of their own (MATLAB through loadlibrary; torch / C callers bring
+ * their own pointers): allocation on the CURRENT device (ocs_set_device), plain copies.  Copies are asynchronous on
+ * `stream` when one is given and the call returns after the copy when it is NULL. */
+int ocs_device_malloc(void **ptr, unsigned long bytes);
+int ocs_device_free(void *ptr);
+int ocs_device_upload(void *dst_device, const void *src_host, unsigned long bytes, void *stream);
+int ocs_device_download(void *dst_host, const void *src_device, unsigned long bytes, void *stream);
+
 /* layout helpers: MATLAB (trajectory-major, [batch][cols][rows]) <-> batch-minor ([cols][rows][batch]),
  * device pointers, rows*cols doubles per trajectory. */
 int ocs_to_batch_minor_dev(const double *src, double *dst, int per_traj, int batch, void *stream);

@@ -33,6 +33,52 @@ classdef GpuMultiDevice < handle
                batch, x0, u, x, J, stats);
          ocs_check(rc);
       end
+      % ---- device-resident blocks (ocs_multi_*_dev): the iterates of single_shooting.m:114,137-150 stay on the GPUs --------
+      function blk = to_devices(obj, A, batch)
+         % A: (rows x batch) or (rows x cols x batch) host array, trajectory index last (MATLAB shape).  Block k goes to
+         % device k in the batch-minor layout of the _dev entry points; blk(k) = struct('p', device pointer, 'n', block size)
+         per = numel(A) / batch;  A = reshape(A, per, batch);
+         for k = 1:numel(obj.devices)
+            lo = libpointer('int32Ptr', 0);  hi = libpointer('int32Ptr', 0);
+            ocs_check(calllib('libocs', 'ocs_multi_shard', obj.h.Value, batch, k - 1, lo, hi));
+            n = double(hi.Value - lo.Value);  bytes = uint64(8 * per * n);
+            ocs_check(calllib('libocs', 'ocs_set_device', obj.devices(k)));
+            st = libpointer('voidPtr');  p = libpointer('voidPtr');
+            ocs_check(calllib('libocs', 'ocs_device_malloc', st, bytes));  ocs_check(calllib('libocs', 'ocs_device_malloc', p, bytes));
+            ocs_check(calllib('libocs', 'ocs_device_upload', st.Value, A(:, lo.Value + 1 : hi.Value), bytes, []));
+            ocs_check(calllib('libocs', 'ocs_to_batch_minor_dev', st.Value, p.Value, per, n, []));
+            ocs_check(calllib('libocs', 'ocs_synchronize'));  calllib('libocs', 'ocs_device_free', st.Value);
+            blk(k) = struct('p', p.Value, 'n', n);  %#ok<AGROW>
+         end
+         ocs_check(calllib('libocs', 'ocs_set_device', obj.devices(1)));
+      end
+      function blk = alloc_on_devices(obj, per, batch)
+         blk = obj.to_devices(zeros(per, batch), batch);
+      end
+      function stats = nlp_objective_dev(obj, integs, probs, ctrls, x0blk, vblk, Jblk, dJdvblk)
+         % [J, dJdv] = nlpObjective(v) on resident blocks; asynchronous, the RCCL reductions enqueued behind the kernels;
+         % stats = {sum J, count, min J, index of the best candidate} (ocs_multi_stats waits for them)
+         gh = cellfun(@(g) g.hnd.Value, integs, 'UniformOutput', false);  ph = cellfun(@(p) p.h.Value, probs, 'UniformOutput', false);
+         ch = cellfun(@(c) c.h.Value, ctrls, 'UniformOutput', false);
+         ocs_check(calllib('libocs', 'ocs_multi_nlp_objective_dev', obj.h.Value, [gh{:}], [ph{:}], [ch{:}], int32([vblk.n]), ...
+               [x0blk.p], [vblk.p], 0, [], [Jblk.p], [dJdvblk.p], 1));
+         stats = zeros(4, 1);
+         [rc, ~, stats] = calllib('libocs', 'ocs_multi_stats', obj.h.Value, stats);  ocs_check(rc);
+      end
+      function A = from_devices(obj, blk, per)
+         % the blocks back as one (per x batch) host array
+         A = zeros(per, sum([blk.n]));  at = 0;
+         for k = 1:numel(obj.devices)
+            ocs_check(calllib('libocs', 'ocs_set_device', obj.devices(k)));
+            n = blk(k).n;  bytes = uint64(8 * per * n);  st = libpointer('voidPtr');
+            ocs_check(calllib('libocs', 'ocs_device_malloc', st, bytes));
+            ocs_check(calllib('libocs', 'ocs_to_traj_major_dev', blk(k).p, st.Value, per, n, []));
+            part = zeros(per, n);
+            [rc, part] = calllib('libocs', 'ocs_device_download', part, st.Value, bytes, []);  ocs_check(rc);
+            calllib('libocs', 'ocs_device_free', st.Value);  A(:, at + 1 : at + n) = part;  at = at + n;
+         end
+         ocs_check(calllib('libocs', 'ocs_set_device', obj.devices(1)));
+      end
       function [J, dJdv, stats] = nlp_objective(obj, integs, probs, ctrls, x0, v)   % single_shooting.m:137-150
          batch = size(v, 2);  J = zeros(batch, 1);  dJdv = zeros(size(v));  stats = zeros(4, 1);
          gh = cellfun(@(g) g.hnd.Value, integs, 'UniformOutput', false);  ph = cellfun(@(p) p.h.Value, probs, 'UniformOutput', false);

@@ -115,6 +115,10 @@ _SIG = {
                                               C.POINTER(vp), C.c_int, ip, C.POINTER(vp), C.POINTER(vp), C.c_int]),
     "ocs_multi_fb_sweep_dev": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), ip, C.POINTER(vp), vp, C.POINTER(vp),
                                          C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.c_int]),
+    "ocs_device_malloc": (C.c_int, [C.POINTER(vp), C.c_ulong]),
+    "ocs_device_free": (C.c_int, [vp]),
+    "ocs_device_upload": (C.c_int, [vp, vp, C.c_ulong, vp]),
+    "ocs_device_download": (C.c_int, [vp, vp, C.c_ulong, vp]),
     "ocs_copy_dev": (C.c_int, [vp, vp, C.c_long, vp]),
     "ocs_to_batch_minor_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),
     "ocs_to_traj_major_dev": (C.c_int, [vp, vp, C.c_int, C.c_int, vp]),

@@ -496,6 +496,32 @@ int ocs_compute_adjoints(ocs_integrator g, ocs_problem p, int batch, const doubl
   return OCS_OK;
 }
 
+int ocs_device_malloc(void** ptr, unsigned long bytes) {
+  if (!ptr || bytes == 0) return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(require_device());
+  *ptr = nullptr;
+  HIP_TRY(hipMalloc(ptr, (size_t)bytes));
+  return OCS_OK;
+}
+int ocs_device_free(void* ptr) {
+  if (ptr) HIP_TRY(hipFree(ptr));
+  return OCS_OK;
+}
+int ocs_device_upload(void* dst, const void* src, unsigned long bytes, void* stream) {
+  if (!dst || !src) return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(require_device());
+  if (stream) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+  else HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyHostToDevice));
+  return OCS_OK;
+}
+int ocs_device_download(void* dst, const void* src, unsigned long bytes, void* stream) {
+  if (!dst || !src) return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(require_device());
+  if (stream) HIP_TRY(hipMemcpyAsync(dst, src, (size_t)bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+  else HIP_TRY(hipMemcpy(dst, src, (size_t)bytes, hipMemcpyDeviceToHost));
+  return OCS_OK;
+}
+
 int ocs_copy_dev(const double* src, double* dst, long n, void* stream) {
   if (!src || !dst || n < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(require_device());

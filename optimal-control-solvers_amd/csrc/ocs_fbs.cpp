@@ -531,9 +531,12 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // start with a look at sweep k's device counter: if no instance was left, they return at once (a sweep over
   // converged instances would change nothing anyway -- they are frozen -- but would cost its full time).
   bool spec_done = false;
-  if (fusedup && nwin == 1 && fuo == 0 &&
-      (fold || (costate_forms_midpoints(pd, N, batch) && forward_gate_supported(pd, gd, batch)))) {
+  // (every state pass of the sweep takes the gate -- the wave-specialised kernels, split passes, the lane kernel of any
+  //  plugin -- so the loop is the same for every problem: what differs is whether the pchip midpoints of x are a kernel
+  //  of their own)
+  if (fusedup && nwin == 1 && (fold || forward_gate_any(pd))) {
     const int nsw = opt->nSWEEPS;
+    const bool ownx = fuo == 0 && costate_forms_midpoints(pd, N, batch);   // midpoints inside the costate / control kernels
     f->last_path = fold ? 4 : 2;
     if (f->h_nact_cap < nsw) {
       if (f->h_nact) (void)hipHostFree(f->h_nact);
@@ -583,9 +586,11 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       fo.no_cost_row = opt->cost_row == 0;
       fo.gate = gate;
       LAUNCH_TRY(launch_forward(pd, gd, batch, x0, f->ugrid.d(), xaug, J, fo, s));
-      LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, nullptr, f->ugrid.d(), status, f->dump.d(), lam, s, 0, tb.PR,
+      const double* xmid = ownx ? nullptr : f->xmid.d();
+      if (!ownx) LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s, 0, gate));
+      LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, xmid, f->ugrid.d(), status, f->dump.d(), lam, s, 0, tb.PR,
                                 gate));
-      LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, nullptr, lam, f->ugrid.d(), status, f->metric.d(),
+      LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, xmid, lam, f->ugrid.d(), status, f->metric.d(),
                                      opt->uRelTol, opt->uAbsTol, s, 0, gate, om));
       LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
                                     mc, dslots + (sweep - 1), s, 0, gate));

@@ -162,9 +162,10 @@ __device__ static inline void pchip_mid_run(const PchipTab& T, const double* V, 
 // blockIdx.y = run of kPchipRun intervals
 __global__ __launch_bounds__(256) void k_pchip_mid(PchipTab T, int nrows, int ld, int batch,
                                                    const double* __restrict__ TM, const double* __restrict__ V,
-                                                   double* __restrict__ out, int ldb) {
+                                                   double* __restrict__ out, int ldb, const int* __restrict__ gate) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int i0 = blockIdx.y * kPchipRun;
+  if (gate && *gate == 0) return;
   if (b >= batch || i0 >= T.n - 1) return;
   const size_t B = (size_t)(ldb ? ldb : batch);  // row distance (a window of a larger batch) / trajectories here
   for (int r = 0; r < nrows; ++r) {
@@ -194,10 +195,12 @@ struct CostateArgs {
   double* dump;        // [B] scratch for their stores
   double* lam;         // [N+1][nS][B]
   int ld;              // row distance when the launch covers a window of a larger batch; 0 = batch
+  const int* gate = nullptr;   // optional: the launch does nothing if *gate == 0
 };
 
 template <class P, int PF>
 __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
+  if (a.gate && *a.gate == 0) return;
   constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC;
   using Rec = StepRec<NTC>;
   const int b0 = blockIdx.x * 64 + threadIdx.x;

@@ -35,9 +35,9 @@ static inline int hip_rc3(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 static PchipTab make_tab(const FbsTables& t) { return PchipTab{t.n, t.TN, t.HN, t.W1, t.W2, t.IH}; }
 
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s,
-                     int ldb) {
+                     int ldb, const int* gate) {
   k_pchip_mid<<<dim3((batch + 255) / 256, (t.n - 1 + kPchipRun - 1) / kPchipRun), dim3(256), 0, s>>>(
-      make_tab(t), nrows, ld, batch, t.TM, V, out, ldb);
+      make_tab(t), nrows, ld, batch, t.TM, V, out, ldb, gate);
   return hip_rc3(hipGetLastError());
 }
 
@@ -65,11 +65,13 @@ int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const dou
                                : launch_costate_scan_u(p, g, batch, x, ldx, PR, u, frozen, lam, s, gate);
   }
   // the wave-specialised kernel while its workgroups (one per 64/nS instances) fit on the chip in two rounds
-  if (p.functor != Functor::User && costate_forms_midpoints(p, g.N, batch))
+  // (launch_costate_pl has no gate: a gated pass with the midpoints given takes the lane kernel below)
+  if (p.functor != Functor::User && costate_forms_midpoints(p, g.N, batch) && !(xmid && gate))
     return xmid ? launch_costate_pl(p, g, batch, x, ldx, xmid, frozen, dump, lam, ldb, s)
                 : launch_costate_plx(p, g, batch, x, ldx, PR, frozen, dump, lam, ldb, s, gate);
-  if (!xmid || gate) return -1;
-  const CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam, ldb};
+  if (!xmid) return -1;
+  CostateArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x, ldx, xmid, u, frozen, dump, lam, ldb};
+  a.gate = gate;
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_COSTATE, dim3((batch + 63) / 64), dim3(64), args, s);

@@ -111,6 +111,8 @@ int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const 
                       bool no_cost_row = false, const int* gate = nullptr);
 // whether launch_forward with these shapes runs the one kernel that honours FwdOpts::gate
 bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch);
+// ... any state pass the sweep launches (with FwdOpts::frozen set) honours the gate, LQ excepted
+bool forward_gate_any(const ProblemDesc& p);
 bool rowsplit_supported(Functor f, int nS, int nC);
 int launch_forward_rs(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                       double* x, double* J, hipStream_t s);
@@ -220,7 +222,7 @@ struct FbsTables {   // pchip node tables of an integrator grid, device pointers
 };
 // ldb: row distance of V / out when the call covers a window of a larger batch (0 = batch)
 int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const double* V, double* out, hipStream_t s,
-                     int ldb = 0);
+                     int ldb = 0, const int* gate = nullptr);
 bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch);
 // fb_sweep with the control update folded into the state pass (ocs_fold_kernel.hpp) and the convergence test into the
 // costate pass (k_costate_plx, MET): sweeps >= 2 are two kernels
@@ -234,7 +236,7 @@ int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const
 int launch_costate(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* xmid,
                    const double* u, const int* frozen, double* dump, double* lam, hipStream_t s, int ldb = 0,
                    const double* PR = nullptr,   // xmid == NULL with PR: the kernel forms the midpoints (see below)
-                   const int* gate = nullptr);   // only with xmid == NULL
+                   const int* gate = nullptr);
 // metric (optional): [control_grid_parts(N)][B] partial maxima of the weighted change at the grid nodes (error points
 // == nodes), for launch_fbs_advance
 // batched single shooting (ocs_shooting.cpp): per-instance state of the spectral projected gradient iteration,

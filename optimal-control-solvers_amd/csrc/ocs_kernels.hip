@@ -185,15 +185,18 @@ static bool scan_pays(int nS, int N, int batch) {
   return N >= 8;
 }
 
+// the wave-specialised state passes on whole horizons (the two-kernel sweep and the fused control update are built on them)
 bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
   if (p.functor == Functor::LQ) return false;
   return choose_mapping(p, g.N, batch, MAP_AUTO, true, false, true) == MAP_PIPELINE &&
          pipeline_steps(p, g.N, batch, false) == g.N;
 }
+// any state pass the sweep launches with `frozen` set (pipeline kernels, split passes, the lane kernel): FwdOpts::gate
+bool forward_gate_any(const ProblemDesc& p) { return p.functor != Functor::LQ; }
 
 int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u,
                    double* x, double* J, const FwdOpts& o, hipStream_t s) {
-  if (o.gate && (o.mapping != MAP_AUTO || o.uconst || o.Jadd || !forward_gate_supported(p, g, batch))) return -1;
+  if (o.gate && (o.mapping != MAP_AUTO || o.uconst || o.Jadd || !forward_gate_any(p) || !o.frozen)) return -1;
   if (p.functor == Functor::LQ) return launch_forward_lq(p, g, batch, x0, u, x, J, o, s);
   const bool plain = !o.uconst && !o.Jadd;
   // (MAP_SCAN names the adjoint kernel; the state pass of such an integrator is chosen automatically)
@@ -218,9 +221,10 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
     const size_t ldb = o.ld ? o.ld : batch;
     const size_t col = (size_t)(p.nS + 1) * ldb, ucol = (size_t)p.nC * ldb;
     double* xb = x + (size_t)N1 * col;
-    const FwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
-                    p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, o.frozen, o.dump, xb + (size_t)p.nS * ldb,
-                    o.ld};
+    FwdArgs a{g.N - N1, batch, g.REC + (size_t)N1 * rec_stride_host(functor_ntc(p.functor, p.nS)), p.ps, p.pb,
+              p.pmask, xb, u + (size_t)(2 * N1) * ucol, xb, J, nullptr, o.frozen, o.dump, xb + (size_t)p.nS * ldb,
+              o.ld};
+    a.gate = o.gate;
     if (p.functor == Functor::User) {
       void* args[] = {(void*)&a};
       return jit_launch(p.user, UK_FWD_X, dim3((batch + 63) / 64), dim3(64), args, s);
@@ -233,7 +237,8 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
     return launch_forward_rs(p, g, batch, x0, u, x, J, s);
   }
   if (o.uconst && !x) return -1;
-  const FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.frozen, o.dump, nullptr, o.ld};
+  FwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, o.Jadd, o.frozen, o.dump, nullptr, o.ld};
+  a.gate = o.gate;
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     const int kid = o.uconst ? UK_FWD_UCONST : (x ? UK_FWD_X : UK_FWD_J);

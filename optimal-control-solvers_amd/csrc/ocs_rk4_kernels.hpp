@@ -66,6 +66,8 @@ struct FwdArgs {
                         //               kernel's last column; default 0, RK4Integrator.m:33)
   int ld;               // distance between rows of the batch-minor arrays when it is not `batch` (a launch on a
                         // window of a larger batch: pointers are offset, `batch` counts the window); 0 = batch
+  const int* gate = nullptr;   // optional: the launch does nothing if *gate == 0 (a sweep of fb_sweep enqueued before the
+                               // host knew that the sweep before it had left no instance active)
 };
 
 // Lanes past the end of the batch are clamped onto the last trajectory: they recompute it and
@@ -73,6 +75,7 @@ struct FwdArgs {
 // branches (one basic block per chunk, so the scheduler can hoist the prefetch loads).
 template <class P, int CH, int PF, bool OUT_X, bool UCONST>
 __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
+  if (a.gate && *a.gate == 0) return;
   constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC;
   using Rec = StepRec<NTC>;
   const int b0 = blockIdx.x * 64 + threadIdx.x;

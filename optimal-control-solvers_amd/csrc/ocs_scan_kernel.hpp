@@ -134,10 +134,14 @@ constexpr int kScanRec = 16;       // doubles per record: {h, h/2, h/6, h/3 | s4
 constexpr int kScanPadFront = 136; // zero records before step 0 (>= the steps of a superblock + 1: 16 x 4 in
                                    // k_backward_scan, 8 x 4 x 4 in k_backward_fcs)
 constexpr int kScanPadBack = 8;    // and after step N-1 (a wave copies 8 records per chunk)
+// Checkpoints of a chunk's upper L - 1 steps integrated again from the first instead of read (k_backward_scan): 8 nS / L
+// bytes of checkpoint traffic per (trajectory, step) instead of 8 nS, for four more evaluations of the row's right-hand
+// side.  Measured at BL-2 (batch 4096, nS = 4): buffers that rotate through HBM 94.5 -> 89.2 us, one buffer set re-used
+// from the memory-side cache 79.9 -> 81.0 us; nS = 1: 70.3 -> 66.8 / 69.2 -> 66.7 us (profiles/r04f_xrc.log).
 #ifndef OCS_SCAN_XRC
-#define OCS_SCAN_XRC 0
+#define OCS_SCAN_XRC 1
 #endif
-constexpr bool kScanXRC = OCS_SCAN_XRC != 0;   // checkpoints of a chunk's upper steps recomputed instead of read (k_backward_scan)
+constexpr bool kScanXRC = OCS_SCAN_XRC != 0;
 
 // W waves per workgroup (chunks per superblock), L steps per chunk
 // ABL (diagnostic builds, -DOCS_SCAN_ABL): 1 no stores, 2 no phase 3, 3 no phase 1, 4 no loads, 5 no barrier/phase 2

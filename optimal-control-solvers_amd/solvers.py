@@ -127,10 +127,16 @@ def single_shooting(prob, x0, tspan, nCONTROL_PTS, **kw):
 
     hist = []
 
+    seen = {}
+
     def fun(v):                                                                  # nlpObjective :137-150
         J, dJdv, x0n = nlp_objective(integrator, prob, control, x0, v, FreeInitStates)
         hist.append(J)
+        seen[np.asarray(v, dtype=np.float64).tobytes()] = J
         return J, dJdv
+
+    class _StepBelowTolX(Exception):
+        pass
 
     # TolX (:20, fmincon's step tolerance): SLSQP has no such option -- the iteration is ended from the callback when
     # an iterate moved by less than TolX in every coefficient.  TolFun (:21) goes to SLSQP's ftol, the tolerance on the
@@ -143,10 +149,18 @@ def single_shooting(prob, x0, tspan, nCONTROL_PTS, **kw):
         last["v"] = np.array(vk, dtype=np.float64)
         if opt["TolX"] and 0.0 < step < opt["TolX"]:
             last["stopped"] = True
-            raise StopIteration
+            raise _StepBelowTolX
 
-    res = minimize(fun, v0, jac=True, method="SLSQP", bounds=bounds, constraints=cons, callback=cb,
-                   options={"ftol": opt["TolFun"] * 1e-3, "maxiter": opt["MaxIter"], "disp": bool(opt["Reporting"])})
+    try:
+        res = minimize(fun, v0, jac=True, method="SLSQP", bounds=bounds, constraints=cons, callback=cb,
+                       options={"ftol": opt["TolFun"] * 1e-3, "maxiter": opt["MaxIter"], "disp": bool(opt["Reporting"])})
+    except _StepBelowTolX:
+        from scipy.optimize import OptimizeResult
+        vl = last["v"]
+        Jl = seen.get(vl.tobytes())
+        if Jl is None:
+            Jl = fun(vl)[0]
+        res = OptimizeResult(x=vl, fun=Jl, nfev=len(hist), success=True, message="step smaller than TolX")
     vOpt = res.x
     soln = {"J": -res.fun if MinMax == "Max" else res.fun}                       # :117-119
     nV = vOpt.size - nFREE

@@ -278,6 +278,50 @@ class Gen1Functions:
         self.ControlBounds = self._b
 
 
+class NumpyTwin:
+    """The Gen-2 plugin methods of OCProblem/OCProblem.m:8-21 -- F, dFdx_times_vec, dFdu_times_vec -- as NumPy callables built
+    from the symbolic Jacobians with lambdify (columns vectorised, same signatures as oracle/np_twin's problem classes):
+    what the generated device source is tested against (oracle/np_twin.RK4IntegratorNP integrates it)."""
+
+    def __init__(self, gen):
+        nS, nC, names = gen["nS"], gen["nC"], gen["param_names"]
+        t, x, lam, u, psym = symbols(nS, nC, names)
+        self.nS, self.nC = nS, nC
+        pv = [float(v) for v in gen["params"]]
+        ps = [psym[n] for n in names]
+        f, g = gen["stateRHS"], gen["objective"]
+        args = [t, *x, *u, *ps]
+        self._F = sp.lambdify(args, [*f, g], "numpy")
+        self._Jx = sp.lambdify(args, [[sp.diff(e, xj) for xj in x] for e in [*f, g]], "numpy")   # (nS+1) x nS
+        self._Ju = sp.lambdify(args, [[sp.diff(e, uj) for uj in u] for e in [*f, g]], "numpy")   # (nS+1) x nC
+        self._pv = pv
+
+    def _call(self, fn, t, y, u):
+        t = np.atleast_1d(np.asarray(t, dtype=np.float64))
+        y, u = np.atleast_2d(y), np.atleast_2d(u)
+        return t, fn(t, *[y[i] for i in range(self.nS)], *[u[j] for j in range(self.nC)], *self._pv)
+
+    def F(self, t, y, u):
+        t, out = self._call(self._F, t, y, u)
+        return np.vstack([np.broadcast_to(np.asarray(o, dtype=np.float64), t.shape) for o in out])
+
+    def _contract(self, M, v, t, ncols):
+        out = np.zeros((ncols, t.size))
+        for i in range(self.nS + 1):
+            for j in range(ncols):
+                out[j] += np.broadcast_to(np.asarray(M[i][j], dtype=np.float64), t.shape) * v[i]
+        return out
+
+    def dFdx_times_vec(self, t, y, u, v):
+        t, M = self._call(self._Jx, t, y, u)
+        g = self._contract(M, np.atleast_2d(v), t, self.nS)
+        return np.vstack([g, np.zeros((1, t.size))])
+
+    def dFdu_times_vec(self, t, y, u, v):
+        t, M = self._call(self._Ju, t, y, u)
+        return self._contract(M, np.atleast_2d(v), t, self.nC)
+
+
 def make_from_symbolic(symObjective, symStateRHS, nStates, nControls, params, bounds, create=True, **kw):
     """prob = make_from_symbolic(symObjective, symStateRHS, nStates, nControls, params, bounds)   make_from_symbolic.m:1-2
 
@@ -293,4 +337,5 @@ def make_from_symbolic(symObjective, symStateRHS, nStates, nControls, params, bo
                        control_from_costate=gen["control_from_costate"])
     prob.generated = gen
     prob.gen1 = Gen1Functions(gen)
+    prob.numpy_twin = NumpyTwin(gen)
     return prob

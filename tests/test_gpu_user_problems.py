@@ -403,7 +403,7 @@ def test_fb_sweep_full_vector_plugin_on_the_vector_mappings(ocs, oracle, N, batc
     """fb_sweep.m:79-115 for a plugin given as the three full-vector methods + ocs_ControlChar (no row structure declared):
     vector-lane state pass with the frozen / gate arguments (k_forward_pv), costate pass as a scan with dense step maps
     (k_costate_vscan: pchip midpoints of x formed inside, control samples read), ControlChar on the grid, bookkeeping; sweeps
-    enqueued one ahead where the batch is whole tiles (path 2), else kernel by kernel with the same costate kernel (path 1).
+    enqueued ahead (path 2; a ragged batch runs the lane state pass and the lane costate pass inside the same loop).
     Per instance against the oracle and the registry problem of the same equations."""
     c, r, m = 1.5, 0.05, [3.0, 2.5]
     rng = np.random.default_rng(N + batch)
@@ -415,7 +415,7 @@ def test_fb_sweep_full_vector_plugin_on_the_vector_mappings(ocs, oracle, N, batc
     gu, gr = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
     su = ocs.fb_sweep_batch(pu, x0, tspan, opts, integrator=gu)
     sr = ocs.fb_sweep_batch(reg, x0, tspan, opts, integrator=gr)
-    assert ocs.fb_sweep_path(gu) == (2 if batch % 64 == 0 else 1)
+    assert ocs.fb_sweep_path(gu) == 2   # (ragged batches too since round 4: the lane kernels take the gate of a sweep enqueued ahead)
     assert np.array_equal(su["sweeps"], sr["sweeps"]) and np.all(su["sweeps"] > 0)
     for k, tol in (("J", 1e-11), ("x", 1e-10), ("lam", 1e-10), ("u", 1e-10)):
         assert relerr(su[k], sr[k]) < tol, k
@@ -518,3 +518,52 @@ def test_predator_prey_generated_from_symbols_equals_hand_written_plugin(ocs, or
     b = int(np.flatnonzero(ok)[0])
     uc = g1.ControlChar(ts, r["x"][:, :, b], r["lam"][:, :, b])
     assert relerr(uc, r["u"][:, :, b]) < 1e-9
+
+
+def test_coupled_six_state_three_control_plugin(ocs, oracle):
+    """OCProblem.m:8-21 puts no limit on the shapes: a coupled plugin with nS = 6, nC = 3 (generated from symbols,
+    tests/user_problems.ring6_symbolic) runs the lane kernels -- integrator passes against the NumPy twin to 1e-12 -- and
+    fb_sweep runs it with the fused control update and sweeps enqueued ahead (path 2: every state pass takes the gate now),
+    equal to the kernel-by-kernel sequence with a host round trip per sweep (path 1) in sweep counts and to round-off."""
+    import importlib
+    from tests.user_problems import ring6_symbolic
+    sym = importlib.import_module("ocs_amd.symbolic")
+    g, f, vals = ring6_symbolic(sym)
+    bounds = [[0.0, 1.0]] * 3
+    prob = ocs.make_from_symbolic(g, f, 6, 3, vals, bounds)
+    assert prob.generated["form"] == "vector" and prob.generated["has_control_char"] and not prob.generated["control_from_costate"]
+    rng = np.random.default_rng(66)
+    N, batch = 160, 130
+    tspan = oracle.linspace(0, 4, N + 1)
+    u, x0 = rng.uniform(0.0, 0.8, (3, 2 * N + 1, batch)), rng.uniform(0.6, 1.8, (6, batch))
+    gi = ocs.RK4Integrator(tspan)
+    x, J = gi.compute_states(prob, x0, u)
+    lam, dJdu = gi.compute_adjoints(prob, u)
+    twin, ti = prob.numpy_twin, tw.RK4IntegratorNP(tspan)
+    for b in (0, 64, batch - 1):
+        xo, Jo = ti.compute_states(twin, x0[:, b], u[:, :, b])
+        lamo, do = ti.compute_adjoints(twin, u[:, :, b])
+        assert relerr(x[:, :, b], xo) < RTOL and abs(J[b] - Jo) < RTOL * max(1, abs(Jo))
+        assert relerr(lam[:, :, b], lamo) < RTOL and relerr(dJdu[:, :, b], do) < RTOL
+    # the undamped iteration of fb_sweep.m:79-87 does not converge on this problem over [0, 4] (on neither path); the damped
+    # update (uRelax, an extension that is off by default) does.  Both loops: the same iteration, sweep by sweep.
+    opt = {"nERROR_PTS": N + 1, "nINTERP_PTS": 41, "nSWEEPS": 120, "uRelax": 0.35}
+    X0 = rng.uniform(0.6, 1.8, (6, 96))
+    g2, g1 = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
+    s2 = ocs.fb_sweep_batch(prob, X0, tspan, opt, integrator=g2)
+    s1 = ocs.fb_sweep_batch(prob, X0, tspan, dict(opt, fused_update_off=1), integrator=g1)
+    assert ocs.fb_sweep_path(g2) == 2 and ocs.fb_sweep_path(g1) == 1
+    ok = s2["sweeps"] > 0
+    assert np.array_equal(s2["sweeps"], s1["sweeps"])
+    mc2, mc1 = s2["maxChange"][:8], s1["maxChange"][:8]     # the "Normalized change in u" of :109, first sweeps, every instance
+    assert np.all(np.isfinite(mc2)) and np.allclose(mc2, mc1, rtol=1e-7, atol=0)
+    assert ok.mean() > 0.5, ok.mean()
+    for k in ("J", "x", "lam", "u"):
+        assert relerr(s2[k][..., ok], s1[k][..., ok]) < 1e-9, k
+    # the converged control satisfies its own definition (ControlChar of the returned x, lam with the clamp of :111)
+    b = int(np.flatnonzero(ok)[0])
+    tq = oracle.linspace(0, 4, 41)
+    from scipy.interpolate import PchipInterpolator
+    xq = np.vstack([PchipInterpolator(tspan, s2["x"][r, :, b])(tq) for r in range(6)])
+    lq = np.vstack([PchipInterpolator(tspan, s2["lam"][r, :, b])(tq) for r in range(6)])
+    assert relerr(prob.gen1.ControlChar(tq, xq, lq), s2["u"][:, :, b]) < 1e-5   # (to the sweep's tolerance: the damped fixed point)

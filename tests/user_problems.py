@@ -237,3 +237,18 @@ def lq_matrices(nS, nC, seed=20260405):
     q = rng.uniform(0.5, 1.5, nS)
     rdiag = rng.uniform(1.0, 2.0, nC)
     return A, Bu, q, rdiag
+
+
+def ring6_symbolic(sym):
+    """A coupled problem beyond the vector mappings (nS = 6 > 4, nC = 3 > 2), from symbols: six logistic stocks on a ring with
+    diffusive exchange, three harvest efforts (effort j works stocks j and j + 3), discounted quadratic objective.
+    Returns (objective, stateRHS, params) for optimal-control-solvers_amd/symbolic.py."""
+    import sympy as sp
+    names = ["r", "kap", "c1", "c2", "c3"] + [f"m{k + 1}" for k in range(6)]
+    t, x, lam, u, p = sym.symbols(6, 3, names)
+    f = [x[i] * (p[f"m{i + 1}"] - x[i]) + p["kap"] * (x[(i + 1) % 6] - 2 * x[i] + x[(i - 1) % 6]) - u[i % 3] * x[i]
+         for i in range(6)]
+    g = sp.exp(-p["r"] * t) * (sum((x[i] - 1) ** 2 for i in range(6)) + sum(p[f"c{j + 1}"] * u[j] ** 2 for j in range(3)))
+    vals = {"r": 0.05, "kap": 0.3, "c1": 1.5, "c2": 2.0, "c3": 1.2,
+            **{f"m{k + 1}": v for k, v in enumerate([3.0, 2.5, 2.0, 2.8, 2.2, 1.8])}}
+    return g, f, vals
