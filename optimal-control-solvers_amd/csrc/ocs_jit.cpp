@@ -316,6 +316,40 @@ int ocs_problem_create_from_source(ocs_problem* out, const char* source, int nS,
   for (int k = 0; k < nparams; ++k) p->user2func[k] = k;
   p->bounds.assign(control_bounds, control_bounds + 2 * nC);
   p->version = next_version();
+  // Flag bit 2 is a declaration the fold kernels rely on (they pass u = 0 to ocs_row_dFdy and x = 0 to ocs_ControlChar).
+  // Its dFdy half is probed here: (dF/dy)' v of the row functions at a few random points must not change with u.
+  // (The ControlChar half -- no dependence on x -- is not probed; symbolic.py derives both from the expressions.)
+  if (has_control_char & 4) {
+    const int k = 4, nAug = nS + 1;
+    std::vector<double> t(k), y((size_t)nAug * k), u1((size_t)nC * k), u2((size_t)nC * k), v((size_t)nAug * k), g1((size_t)nAug * k),
+        g2((size_t)nAug * k);
+    unsigned long long sd = 0x9E3779B97F4A7C15ull;
+    auto rnd = [&sd]() {
+      sd = sd * 6364136223846793005ull + 1442695040888963407ull;
+      return (double)(sd >> 11) / 9007199254740992.0;
+    };
+    for (int j = 0; j < k; ++j) t[j] = 0.5 + j;
+    for (double& q : y) q = 0.5 + rnd();
+    for (double& q : v) q = 0.5 + rnd();
+    for (int j = 0; j < nC * k; ++j) {
+      const double lo = control_bounds[j % nC], hi = control_bounds[nC + j % nC];
+      const bool fin = std::isfinite(lo) && std::isfinite(hi);
+      u1[j] = fin ? lo + 0.25 * (hi - lo) : 0.3;
+      u2[j] = fin ? lo + 0.75 * (hi - lo) : 0.9;
+    }
+    int rc2 = ocs_problem_dFdx_times_vec(p, k, t.data(), y.data(), u1.data(), v.data(), g1.data());
+    if (rc2 == OCS_OK) rc2 = ocs_problem_dFdx_times_vec(p, k, t.data(), y.data(), u2.data(), v.data(), g2.data());
+    if (rc2 != OCS_OK) {
+      ocs_problem_destroy(p);
+      return rc2;
+    }
+    for (size_t q = 0; q < g1.size(); ++q)
+      if (g1[q] != g2[q] && !(std::isnan(g1[q]) && std::isnan(g2[q]))) {
+        ocs_problem_destroy(p);
+        return fail(OCS_ERR_INVALID, "flag bit 2 (control from the costate alone) declares that ocs_row_dFdy does not read u, but "
+                                     "(dF/dy)' v changes with u (row %d): drop the declaration", (int)(q % nAug));
+      }
+  }
   *out = p;
   return OCS_OK;
 }

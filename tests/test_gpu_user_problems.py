@@ -567,3 +567,19 @@ def test_coupled_six_state_three_control_plugin(ocs, oracle):
     xq = np.vstack([PchipInterpolator(tspan, s2["x"][r, :, b])(tq) for r in range(6)])
     lq = np.vstack([PchipInterpolator(tspan, s2["lam"][r, :, b])(tq) for r in range(6)])
     assert relerr(prob.gen1.ControlChar(tq, xq, lq), s2["u"][:, :, b]) < 1e-5   # (to the sweep's tolerance: the damped fixed point)
+
+
+def test_false_declarations_are_refused(ocs):
+    """ocs_problem_create_from_source probes the dFdy half of flag bit 2 (control from the costate alone): a plugin whose
+    (dF/dy)'v reads u cannot claim it.  Per-trajectory parameters are refused for plugins that tabulate a time coefficient
+    from the shared parameter block (ocs_tcoef / ocs_cc_tcoef)."""
+    from tests.user_problems import PREDPREY_TC_SRC, PROPHARVEST_ROWS_CC_SRC
+    kw = dict(has_control_char=True, row_separable=True)
+    ocs.UserProblem(PROPHARVEST_ROWS_CC_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], BOUNDS, **kw)           # without the claim: fine
+    with pytest.raises(ocs.OcsError, match="dFdy does not read u"):
+        ocs.UserProblem(PROPHARVEST_ROWS_CC_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], BOUNDS, control_from_costate=True, **kw)
+    pt = ocs.UserProblem(PREDPREY_TC_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS)
+    with pytest.raises(ocs.OcsError, match="tabulated"):
+        pt.set_batch_params([4], np.full((1, 8), 2.0))
+    pn = ocs.UserProblem(PREDPREY_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS)
+    pn.set_batch_params([4], np.full((1, 8), 2.0))                                                 # no tabulated coefficient: allowed
