@@ -100,6 +100,74 @@ def cpu_baseline(tspan, x0, u, target_seconds=12.0):
                            "sample": f"{p1} passes over the first {b1} trajectories of the same batch in {d1:.1f} s"}}, out
 
 
+def live_traffic(timeout_s=150):
+    """HBM bytes per launch of the headline kernels from the PMC counters, COLLECTED BY THIS RUN: two child processes
+    (rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes, as MI355X_MICROARCH.md prescribes; kernel trace only)
+    over scripts/traffic_once.py -- the same kernels on the same shapes -- started before this process touches the GPU.
+    Counters are KiB; both are corrected by the factor the same passes measure on a copy of known size with this path's
+    access width (8 B per lane: FETCH_SIZE x 2.0 on gfx950, WRITE_SIZE x 1.0).  Returns None if rocprofv3 is missing or a
+    pass fails (the line then carries the replayed figure of profiles/, labelled as such)."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    work = tempfile.mkdtemp(prefix="ocs_traffic_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    per = {}
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(work, counter)
+            r = subprocess.run(["rocprofv3", "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", out, "--",
+                                sys.executable, os.path.join(ROOT, "scripts", "traffic_once.py")],
+                               cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=timeout_s)
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                return None
+            cal_bytes = None
+            for ln in r.stdout.decode(errors="replace").splitlines():
+                if ln.startswith("calibration bytes per launch"):
+                    cal_bytes = float(ln.split(":")[1])
+            rows = {}
+            with open(max(files, key=os.path.getmtime)) as fh:
+                for row in csv.DictReader(fh):
+                    if row["Counter_Name"] != counter:
+                        continue
+                    nm = row["Kernel_Name"]
+                    key = ("copy" if "k_copy8" in nm else "fwd" if "k_forward_p2" in nm else "bwd" if "k_backward_scan" in nm else
+                           "fcc" if "k_forward_cc" in nm else "cst" if "k_costate" in nm else None)
+                    if key:
+                        rows.setdefault(key, []).append((int(row["Dispatch_Id"]), float(row["Counter_Value"]) * 1024.0))
+            if cal_bytes is None or "copy" not in rows or len(rows.get("bwd", [])) < 17 or len(rows.get("fwd", [])) < 17:
+                return None
+            for k in rows:
+                rows[k] = [v for _, v in sorted(rows[k])]
+            fac = cal_bytes / (sum(rows["copy"]) / len(rows["copy"]))
+            mean = lambda v: sum(v) / len(v)
+            per[counter] = {"factor": fac,
+                            "fwd_one_set": mean(rows["fwd"][4:8]) * fac, "bwd_one_set": mean(rows["bwd"][4:8]) * fac,
+                            "fwd_rotating": mean(rows["fwd"][11:17]) * fac, "bwd_rotating": mean(rows["bwd"][11:17]) * fac}
+            for k in ("fcc", "cst"):   # live launches of the sweep only (a gated-off launch moves nothing)
+                if k in rows and max(rows[k]) > 0:
+                    live = [v for v in rows[k] if v > 0.05 * max(rows[k])]
+                    per[counter][k] = mean(live) * fac
+        f, w = per["FETCH_SIZE"], per["WRITE_SIZE"]
+        res = {"source": "collected by this run: rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE (separate passes, kernel trace "
+                         "only) over scripts/traffic_once.py before the timed loops; bytes = counter x 1024 x the factor the same "
+                         "pass measures on ocs_copy_dev (8 B per lane, known byte count)",
+               "fetch_factor": f["factor"], "write_factor": w["factor"]}
+        for k in ("fwd_one_set", "bwd_one_set", "fwd_rotating", "bwd_rotating", "fcc", "cst"):
+            if k in f and k in w:
+                res[k] = {"fetch": f[k], "write": w[k], "hbm_bytes_per_launch": f[k] + w[k]}
+        return res
+    except Exception:
+        return None
+    finally:
+        shutil.rmtree(work, ignore_errors=True)
+
+
 def _shard(ocs, total):
     world, rank = ocs.distributed.world_info()
     lo, hi = ocs.distributed.shard_bounds(total, world, rank)
@@ -529,6 +597,9 @@ def main():
                     help="seconds of untimed passes before the W warm-up steps: the clocks of an idle GPU take a few "
                          "hundred ms to come up, and the K timed steps last only a few ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="do not collect the PMC traffic counters in child processes first (roofline.traffic is then the "
+                         "figure replayed from profiles/)")
     ap.add_argument("--no-fb-sweep", action="store_true", help="skip the secondary legs (fb_sweep, BL-4, BL-5, large batch)")
     args = ap.parse_args()
 
@@ -538,6 +609,7 @@ def main():
     if args.gpus > 1 and world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with --nproc-per-node {args.gpus}")
     import torch.distributed as dist
+    LIVE = live_traffic() if (world == 1 and not args.no_live_traffic and "RANK" not in os.environ) else None
     # OCS_FORCE_COLLECTIVES=1 under torch.distributed.run with ONE process: the process group is created and every
     # collective of the N-rank path (asynchronous objective all-reduce and its drain, barriers, max over ranks, the
     # gathers of the secondary legs) executes on RCCL with world size 1 -- the rehearsal a one-GPU box allows
@@ -653,6 +725,9 @@ def main():
                                       "replayed from that file, not collected by this run)")
             except Exception:
                 traffic = None
+        if LIVE and "bwd_one_set" in LIVE and batch == BATCH:
+            traffic = LIVE["bwd_one_set"]["hbm_bytes_per_launch"]
+            traffic_source = LIVE["source"]
         line = {
             "metric": "RK4 state+costate steps/sec (batch*nSteps)",
             "value": steps_total / dt,
@@ -691,6 +766,8 @@ def main():
                         "pass_pair_frac": (bytes_fwd + bytes_bwd) * args.steps / dt / 1e9 / HBM_PEAK_GBPS},
             "finite": ok,
         }
+        if LIVE:
+            line["traffic_collected_by_this_run"] = LIVE
     # secondary legs: every rank runs them on its shard (collectives inside)
     if not args.no_fb_sweep:
         fb = fb_sweep_metric(ocs, dev)
@@ -709,7 +786,13 @@ def main():
             if one:
                 line["other_configs"]["BL-2 shapes with one state (TestOCProblem, nAug = 2)"] = one
             if rot:
+                if LIVE and "bwd_rotating" in LIVE and batch == BATCH:
+                    rot["roofline"]["traffic"] = LIVE["fwd_rotating"]["hbm_bytes_per_launch"] + LIVE["bwd_rotating"]["hbm_bytes_per_launch"]
+                    rot["roofline"]["traffic_source"] = LIVE["source"]
                 line["other_configs"]["BL-2 pass pair over 3 rotating buffer sets (no reuse across steps: HBM, not Infinity Cache)"] = rot
+            if LIVE and "fcc" in LIVE and "cst" in LIVE and fb["batch_per_gpu"] == 16384:
+                fb["roofline"]["traffic"] = LIVE["fcc"]["hbm_bytes_per_launch"] + LIVE["cst"]["hbm_bytes_per_launch"]
+                fb["roofline"]["traffic_source"] = LIVE["source"]
             if ssr:
                 line["other_configs"]["strong-scaling readiness (8-GPU shard sizes on one GPU)"] = ssr
     if rank == 0:
