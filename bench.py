@@ -114,6 +114,10 @@ def live_traffic(timeout_s=150):
     import tempfile
     if shutil.which("rocprofv3") is None:
         return None
+    # under a profiler the preloaded tool library has already initialised the GPU in THIS process: it must not start
+    # children that exec (and a profile of bench.py is about the timed loops anyway)
+    if "rocprof" in os.environ.get("LD_PRELOAD", "").lower() or any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ):
+        return None
     work = tempfile.mkdtemp(prefix="ocs_traffic_", dir="/tmp")
     env = dict(os.environ, TMPDIR="/tmp")
     per = {}

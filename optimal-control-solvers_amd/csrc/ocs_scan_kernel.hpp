@@ -239,36 +239,32 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
     else
       asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NST) : "memory");
     const double* rw = &rcs[slot][wave][0];
-    // (kScanXRC) only the checkpoint of the chunk's first step was read: the other L - 1 are integrated again from it,
-    // RK4Integrator.m:37-50 on this row -- 8 (nS) bytes per (trajectory, step) instead of 8 nS of checkpoint traffic
+    // ---------------- phase 1: stage states and the chunk map ----------------
+    // Steps in ascending order: (kScanXRC) only the checkpoint of the chunk's first step was read, the next one comes out
+    // of the stage evaluations the step map needs anyway plus one more right-hand side (RK4Integrator.m:49-50 on this row)
+    // -- 8 nS / L instead of 8 nS bytes of checkpoint traffic per (trajectory, step).  The chunk map is composed from the
+    // bottom: lam_lo = A lam_(above the steps so far) + Bq.
     double xs[L];
     xs[0] = d.x[0];
-#pragma unroll
-    for (int q = 0; q + 1 < L; ++q) {
-      if (kScanXRC) {
-        const Rc c = rec_of(rw, q);
-        const double xi = xs[q], uA = d.u[2 * q], uM = d.u[2 * q + 1], uB = d.u[2 * q + 2];
-        const double F1 = P::g_row_f(xi, uA, c.tA, rp);
-        const double F2 = P::g_row_f(__builtin_fma(c.hh, F1, xi), uM, c.tM, rp);
-        const double F3 = P::g_row_f(__builtin_fma(c.hh, F2, xi), uM, c.tM, rp);
-        const double F4 = P::g_row_f(__builtin_fma(c.h, F3, xi), uB, c.tB, rp);
-        xs[q + 1] = __builtin_fma(c.h6, ((F1 + 2.0 * F2) + 2.0 * F3) + F4, xi);   // :50
-      } else {
-        xs[q + 1] = d.x[q + 1];
-      }
-    }
-    // ---------------- phase 1: stage states and the chunk map ----------------
     double A = 1.0, Bq = 0.0;
 #pragma unroll
-    for (int q = L - 1; q >= 0 && ABL != 3; --q) {
+    for (int q = 0; q < L && ABL != 3; ++q) {
       const Rc c = rec_of(rw, q);
       const double xi = xs[q], uA = d.u[2 * q], uM = d.u[2 * q + 1], uB = d.u[2 * q + 2];
-      double f = P::g_row_f(xi, uA, c.tA, rp);                 // compute_states :39-46, this row
-      const double Y2 = __builtin_fma(c.hh, f, xi);
-      f = P::g_row_f(Y2, uM, c.tM, rp);
-      const double Y3 = __builtin_fma(c.hh, f, xi);
-      f = P::g_row_f(Y3, uM, c.tM, rp);
-      const double Y4 = __builtin_fma(c.h, f, xi);
+      const double F1 = P::g_row_f(xi, uA, c.tA, rp);           // compute_states :39-46, this row
+      const double Y2 = __builtin_fma(c.hh, F1, xi);
+      const double F2 = P::g_row_f(Y2, uM, c.tM, rp);
+      const double Y3 = __builtin_fma(c.hh, F2, xi);
+      const double F3 = P::g_row_f(Y3, uM, c.tM, rp);
+      const double Y4 = __builtin_fma(c.h, F3, xi);
+      if (q + 1 < L) {
+        if (kScanXRC) {
+          const double F4 = P::g_row_f(Y4, uB, c.tB, rp);
+          xs[q + 1] = __builtin_fma(c.h6, ((F1 + 2.0 * F2) + 2.0 * F3) + F4, xi);   // :50
+        } else {
+          xs[q + 1] = d.x[q + 1];
+        }
+      }
       const Stage s4 = P::template stage<LT>(c.s4, c.h6, c.tB, lamc), s3 = P::template stage<LT>(c.s3, c.h3, c.tM, lamc),
                   s1 = P::template stage<LT>(c.s1, c.h6, c.tA, lamc);
       // row of (dF/dy)'v = a v_r + b; (p, q): the quantity is p lam_{i+1} + q          :73-88
@@ -286,11 +282,15 @@ __global__ __launch_bounds__(W * 64) void k_backward_scan(const BwdArgsScan a) {
       const double g0p = a1 * k1p, g0q = __builtin_fma(a1, k1q, b1);
       const double alpha = (((1.0 + g1p) + g2p) + g3p) + g0p;
       const double beta = ((g1q + g2q) + g3q) + g0q;
-      Bq = __builtin_fma(alpha, Bq, beta);
-      A = alpha * A;
+      Bq = __builtin_fma(A, beta, Bq);
+      A = A * alpha;
       __builtin_amdgcn_sched_barrier(0);   // one step at a time: the temporaries of interleaved steps cost occupancy
-      load_part(sb + 1, dn, slot ^ 1, L - 1 - q);
+      load_part(sb + 1, dn, slot ^ 1, q);
       __builtin_amdgcn_sched_barrier(0);
+    }
+    if (ABL == 3) {
+#pragma unroll
+      for (int q = 1; q < L; ++q) xs[q] = xs[0];
     }
     sm[sb & 1][wave][lane] = double2{A, Bq};
     if (ABL != 5) lds_barrier_sc();

@@ -10,7 +10,7 @@ ROOT=${GRAFT_REPO_ROOT:-$PWD}
 OUT=$ROOT/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-fb-sweep --steps 10 --warmup 2"
+BENCH="python3 $ROOT/bench.py --no-cpu-baseline --no-fb-sweep --no-live-traffic --steps 10 --warmup 2"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -- $BENCH > $OUT/trace.log 2>&1 || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -- $BENCH > $OUT/pmc_fetch.log 2>&1 || exit 1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -- $BENCH > $OUT/pmc_write.log 2>&1 || exit 1
