@@ -403,7 +403,11 @@ def bl2_rotated_metric(ocs, dev, batch=BATCH, nsets=3, reps=20):
         state["k"] += 1
         integ.compute_states_dev(prob, x0, u, x, J)
         integ.compute_adjoints_dev(prob, u, None, lam, dJdu)
-    ocs.distributed.prewarm(step, 0.4, _sync, chunk=nsets * 5)
+    # (the steady state of this memory-bound loop takes ~30 ms to settle after any gap -- the first repetitions after the
+    #  pre-warm of an earlier version ran 0.158 .. 0.150 ms on their way to 0.145: the pre-warm is long, the repetitions follow
+    #  it directly, and the event-bracketed steps for the per-kernel times come last)
+    ocs.distributed.prewarm(step, 0.6, _sync, chunk=nsets * 20)
+    sp, dt = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(step, reps, _sync, inner=nsets * 10))
     nev = 30
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(3)] for _ in range(nev)]
     for k in range(nev):
@@ -416,8 +420,6 @@ def bl2_rotated_metric(ocs, dev, batch=BATCH, nsets=3, reps=20):
     torch.cuda.synchronize()
     t_f = float(np.median([e[0].elapsed_time(e[1]) for e in ev])) * 1e-3
     t_b = float(np.median([e[1].elapsed_time(e[2]) for e in ev])) * 1e-3
-    state["k"] = 0
-    sp, dt = ocs.distributed.spread(ocs.distributed.timed_reps_max_over_ranks(step, reps, _sync, inner=nsets * 4))
     nA = nS + 1
     b_f, b_b = 8 * (nA + 2 * NC) * batch * NSTEPS, 8 * (2 * nA + 4 * NC) * batch * NSTEPS
     return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "buffer_sets": nsets,
