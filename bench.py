@@ -682,12 +682,6 @@ def main():
         one_step(i)
     drain()
     torch.cuda.synchronize()
-    # per-kernel durations (roofline): K untimed steps with HIP events between the two kernels
-    for k in range(args.steps):
-        one_step(k, k)
-    drain()
-    torch.cuda.synchronize()
-    # (HIP event records between the kernels cost a few us of GPU idle time each, so the timed steps below carry none)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -699,6 +693,12 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # per-kernel durations (roofline): K more steps, untimed, with HIP events between the two kernels (an event record between
+    # kernels costs a few us of GPU idle time, so the timed steps above carry none, and these come after them)
+    for k in range(args.steps):
+        one_step(k, k)
+    drain()
+    torch.cuda.synchronize()
     if use_dist:
         tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
