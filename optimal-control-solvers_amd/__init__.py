@@ -19,7 +19,7 @@ from .control import Control, PWLinearControl, PWConstantControl, ChebyshevContr
 from .interp import vectorInterpolant, vectorInterpolant_dev, heval, linspace  # noqa: F401
 from .solvers import (nlp_objective, nlp_objective_dev, single_shooting, single_shooting_batch,  # noqa: F401
                       compute_equilibrium, compute_equilibrium_dev)
-from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, fb_sweep_path, compute_x_lam, compute_x_lam_J  # noqa: F401
+from .sweep import fb_sweep, fb_sweep_batch, fb_sweep_dev, fb_sweep_path, compute_x_lam, compute_x_lam_J, compute_J  # noqa: F401
 from . import distributed  # noqa: F401
 from .multi import MultiDevice  # noqa: F401
 

@@ -68,6 +68,14 @@ def compute_x_lam_J(prob, x0, tspan, ugrid, integrator=None):
     return x[:, :, 0], lam[:, :, 0], float(J[0])
 
 
+def compute_J(prob, x0, tspan, ugrid, integrator=None):
+    """J = compute_J(prob, x0, tspan, u, RelTol, AbsTol)   functions/compute_J.m:1-16: the objective of the state pass alone
+    (the augmented state [x; int objective], :6-15) with u sampled on the 2N+1 grid -- the J of RK4Integrator.compute_states."""
+    integ = integrator or RK4Integrator(tspan)
+    _, J = integ.compute_states(prob, x0, ugrid)
+    return J
+
+
 def _sample_u0(u0, prob, pts_list, batch):
     """u0: callable t -> nC x k, or numeric nC x m (evenly spaced samples -> pchip, fb_sweep.m:61-66)."""
     outs = []

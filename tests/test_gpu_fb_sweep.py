@@ -41,6 +41,7 @@ def test_compute_x_lam_matches_oracle(ocs, oracle):
             assert relerr(x[:, :, b], xo) < 1e-12 and relerr(lam[:, :, b], lo) < 1e-12
             assert abs(J[b] - Jo) < 1e-12 * max(1.0, abs(Jo))
         assert np.all(lam[:, -1, :] == 0.0)  # lam(TF) = 0*x0  compute_x_lam.m:4
+        assert relerr(ocs.compute_J(pg, x0, tspan, u), J) < 1e-13   # functions/compute_J.m: the state pass alone
 
 
 def test_fb_sweep_single_instance_like_the_reference(ocs, oracle):
