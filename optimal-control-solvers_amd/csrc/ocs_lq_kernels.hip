@@ -1656,21 +1656,33 @@ __global__ __launch_bounds__(256) void k_lq_carry(int nS, int nU, int B, int C, 
     if (live && r < nS) out[(size_t)first * SB + (size_t)r * B + b] = v;
   }
   const int nsteps = TRANS ? (last ? C : C - 1) : C - 1;
-  for (int it = 0; it < nsteps; ++it) {
-    const int c = TRANS ? C - 1 - it : it;           // the chunk whose map is applied
-    const int dst = TRANS ? c - 1 : c + 1;           // (-1: `last`)
+  // the matrix and the constants of iteration it + 1 are requested while iteration it computes (registers, then LDS)
+  double mreg[4], areg[8];
+  auto fetch = [&](int it) {
+    const int c = TRANS ? C - 1 - it : it;
     const double* M = MT + (size_t)c * nS * nU;
-    for (int e = threadIdx.x; e < 32 * 32; e += 256) {   // Ms[r][k] = M_c[r][k] (TRANS: M_c[k][r]), zero outside nS x nS
-      const int r = e >> 5, k = e & 31;
-      Ms[e] = (r < nS && k < nS) ? (TRANS ? M[(size_t)k * nU + r] : M[(size_t)r * nU + k]) : 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {   // Ms[r][k] = M_c[r][k] (TRANS: M_c[k][r]), zero outside nS x nS
+      const int e = threadIdx.x + 256 * j, r = e >> 5, k = e & 31;
+      mreg[j] = (r < nS && k < nS) ? (TRANS ? M[(size_t)k * nU + r] : M[(size_t)r * nU + k]) : 0.0;
     }
-    double acc[8];
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int r = 8 * rg + q;
-      acc[q] = (live && r < nS) ? add[(size_t)c * SB + (size_t)r * B + b] : 0.0;
+      areg[q] = (live && r < nS) ? add[(size_t)c * SB + (size_t)r * B + b] : 0.0;
     }
+  };
+  if (nsteps > 0) fetch(0);
+  for (int it = 0; it < nsteps; ++it) {
+    const int c = TRANS ? C - 1 - it : it;           // the chunk whose map is applied
+    const int dst = TRANS ? c - 1 : c + 1;           // (-1: `last`)
+    double acc[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) Ms[threadIdx.x + 256 * j] = mreg[j];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) acc[q] = areg[q];
     __syncthreads();   // Ms and xs complete
+    if (it + 1 < nsteps) fetch(it + 1);
 #pragma unroll 8
     for (int k = 0; k < 32; ++k) {
       const double xk = xs[k * 64 + tl];
@@ -1751,14 +1763,17 @@ static int lq_chunks(int batch, int N, int mapping) {
 // automatic selection: up to 4096 trajectories (C >= 8).  Measured, nS = 32, nC = 4, 2 x 4000 steps, pass pair: 1024 trajectories
 // 6.6 ms (four-wave kernels 28.5), 2048: ~12 (28.6), 4096: 21-23 (28.6); at 8192 the doubled work costs what the shorter chains
 // gain (two-wave kernels 30.3 ms)
-static bool lq_chunked(int batch, int N, int mapping) {
+// z_only: the pass wants nothing but the value at the far end of the horizon (the adjoint of the tail leg of
+// RK4InfiniteIntegrator.m:27-30: lam2(:,1)) -- pass Z and the carries ARE that pass, there is no pass X and no doubled work, so
+// chunks pay as soon as there are two of them (8192 trajectories: 4 chunks, 2048 one-wave groups instead of 1024 exchanging pairs)
+static bool lq_chunked(int batch, int N, int mapping, bool z_only = false) {
   static const int env = [] {
     const char* e = getenv("OCS_LQ_MAP");
     return e ? atoi(e) : 0;
   }();
   if (lq_chunk_forced(mapping)) return lq_chunks(batch, N, mapping) >= 2;
   if (mapping != MAP_AUTO || env != 0) return false;
-  return lq_chunks(batch, N, mapping) >= 8;
+  return lq_chunks(batch, N, mapping) >= (z_only ? 2 : 8);
 }
 
 template <int RT>
@@ -1972,7 +1987,7 @@ int launch_backward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
   a.xck = xck; a.u = u; a.lamT = lamT; a.lam = lam; a.dJdu = dJdu; a.lam0 = o.lam0;
-  if (g.lqws && lq_chunked(batch, g.N, o.mapping))
+  if (g.lqws && lq_chunked(batch, g.N, o.mapping, o.uconst))
     return p.nS <= 16 ? lq_backward_chunked<1>(p, g, batch, xck, u, lamT, lam, dJdu, o, s)
                       : lq_backward_chunked<2>(p, g, batch, xck, u, lamT, lam, dJdu, o, s);
   if (p.nS <= 16) {

@@ -212,3 +212,64 @@ def test_multi_device_several_slots_on_one_gpu(ocs, oracle, monkeypatch, nslots)
     md.compute_states_dev(integs, probs, x0d, ud, xd, Jd)
     md.synchronize()
     assert torch.cuda.current_device() == 0
+
+
+def test_device_buffer_helpers_and_resident_loop_on_two_slots(ocs, oracle, monkeypatch):
+    """ocs_device_malloc / _upload / _download / _free (what a MATLAB host uses to keep blocks on the devices) and the loop of
+    single_shooting.m:114,137-150 on resident blocks over two slots: nlpObjective evaluated repeatedly with the iterate updated
+    on the devices, nothing but the four statistics coming back; fb_sweep on resident blocks of two slots."""
+    import ctypes as C
+
+    import torch
+    lib = ocs._lib.lib
+    h = np.arange(12, dtype=np.float64) * 1.5
+    back = np.zeros_like(h)
+    p = C.c_void_p()
+    assert lib.ocs_device_malloc(C.byref(p), h.nbytes) == 0 and p.value
+    assert lib.ocs_device_upload(p, h.ctypes.data_as(C.c_void_p), h.nbytes, None) == 0
+    assert lib.ocs_device_download(back.ctypes.data_as(C.c_void_p), p, h.nbytes, None) == 0
+    assert np.array_equal(h, back) and lib.ocs_device_free(p) == 0
+    monkeypatch.setenv("OCS_MULTI_ALLOW_DUPLICATES", "1")
+    md = ocs.MultiDevice([0, 0])
+    dev = torch.device("cuda:0")
+    N, nB, B = 64, 8, 150
+    tspan = oracle.linspace(0, 4, N + 1)
+    integs = md.replicate(lambda: ocs.RK4Integrator(tspan))
+    probs = md.replicate(lambda: ocs.TestOCProblem(P, BOUNDS))
+    ctrls = md.replicate(lambda: ocs.ChebyshevControl(integs[0].t, nB, 1))
+    g1, p1, c1 = ocs.RK4Integrator(tspan), ocs.TestOCProblem(P, BOUNDS), ocs.ChebyshevControl(integs[0].t, nB, 1)
+    rng = np.random.default_rng(11)
+    V = 0.05 * rng.normal(size=(nB, B)) / np.arange(1, nB + 1)[:, None]
+    V[0] += 0.4
+    bounds = [md.shard(B, k) for k in range(2)]
+    vb = [torch.tensor(np.ascontiguousarray(V[:, lo:hi]), device=dev) for lo, hi in bounds]
+    x0b = [torch.full((1, hi - lo), 1.2, dtype=torch.float64, device=dev) for lo, hi in bounds]
+    Jb = [torch.empty(hi - lo, dtype=torch.float64, device=dev) for lo, hi in bounds]
+    gb = [torch.empty_like(v) for v in vb]
+    Vs, x0s = torch.tensor(V, device=dev), torch.full((1, B), 1.2, dtype=torch.float64, device=dev)
+    Js, Gs = torch.empty(B, dtype=torch.float64, device=dev), torch.empty_like(Vs)
+    torch.cuda.synchronize()
+    for it in range(4):   # steepest descent with a fixed step, the iterate never leaves the device
+        md.nlp_objective_dev(integs, probs, ctrls, x0b, vb, Jb, gb, reduce=True)
+        st = md.stats()
+        ocs.nlp_objective_dev(g1, p1, c1, x0s, Vs, (), Js, Gs)
+        torch.cuda.synchronize()
+        assert torch.equal(torch.cat(Jb), Js) and torch.equal(torch.cat(gb, dim=1), Gs)
+        assert st["argmin"] == int(torch.argmin(Js)) and st["count"] == B
+        for v, g in zip(vb, gb):
+            v -= 1e-2 * g
+        Vs -= 1e-2 * Gs
+        torch.cuda.synchronize()
+    # fb_sweep on two resident blocks against one solve of the whole batch
+    X0 = rng.uniform(0.8, 1.6, (1, 128))
+    ts2 = oracle.linspace(0, 4.5, 169)
+    ig = md.replicate(lambda: ocs.RK4Integrator(ts2))
+    opt = {"nERROR_PTS": 169, "nINTERP_PTS": 17}
+    blocks = [torch.tensor(np.ascontiguousarray(X0[:, lo:hi]), device=dev) for lo, hi in (md.shard(128, 0), md.shard(128, 1))]
+    outs = md.fb_sweep_dev(ig, probs, blocks, opt, reduce=True)
+    stf = md.stats()
+    ref = ocs.fb_sweep_dev(p1, ocs.RK4Integrator(ts2), torch.tensor(X0, device=dev), opt)
+    torch.cuda.synchronize()
+    assert torch.equal(torch.cat([o["sweeps"] for o in outs]), ref["sweeps"]) and bool((ref["sweeps"] > 0).all())
+    assert torch.equal(torch.cat([o["J"] for o in outs]), ref["J"]) and torch.equal(torch.cat([o["lam"] for o in outs], dim=2), ref["lam"])
+    assert stf["count"] == 128 and stf["argmin"] == int(torch.argmin(ref["J"]))
