@@ -55,7 +55,14 @@ struct FoldCfg {
   static_assert(REC_DBL == 128 && (G == 1 || PR_DBL == 128) && Q * LPB <= 63, "block shapes");
   // wave -> role: the recursion wave shares its SIMD (waves w, w+4, w+8, w+12) with the light roles only
   enum Role { M_ = 0, S_ = 1, P_ = 2, J_ = 3, C_ = 4, U_ = 5 };
+#ifndef OCS_FOLD_ROLEMAP
+#define OCS_FOLD_ROLEMAP 0   // tuning builds: 1 = a control wave on the recursion wave's SIMD in the place of M, 2 = two (M and J out)
+#endif
   __device__ static constexpr int role(int w) {
+    if (G == 1 && OCS_FOLD_ROLEMAP == 1)
+      return w == 1 ? S_ : w == 5 ? P_ : w == 9 ? J_ : w == 14 ? M_ : (w == 0 || (w >= 2 && w <= 4)) ? C_ : U_;
+    if (G == 1 && OCS_FOLD_ROLEMAP == 2)
+      return w == 1 ? S_ : w == 5 ? P_ : w == 10 ? J_ : w == 14 ? M_ : (w == 0 || (w >= 2 && w <= 4)) ? C_ : U_;
     return G == 1 ? (w == 1 ? S_ : w == 5 ? P_ : w == 9 ? J_ : w == 13 ? M_ : (w == 0 || (w >= 2 && w <= 4)) ? C_ : U_)
          : G == 2 ? (w == 0 ? M_ : w == 1 ? S_ : w == 5 ? P_ : w == 9 ? J_ : (w == 2 || w == 3 || w == 4 || w == 6) ? C_ : U_)
                   : (w == 0 ? M_ : w == 1 ? S_ : w == 5 ? P_ : w == 4 ? J_ : (w == 2 || w == 3) ? C_ : U_);
