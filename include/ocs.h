@@ -90,7 +90,9 @@ int ocs_problem_create(ocs_problem *out, int problem_id, int nS, int nC, const d
  * the Gen-1 ControlChar of make_from_symbolic.m:33-38 for a Hamiltonian separable in (x, u)): fb_sweep then runs its
  * two-kernel sweep for the problem (ocs_fb_sweep_path == 4); ocs_ControlChar receives x = zeros, ocs_row_dFdy u = 0 there.
  * A compile error returns OCS_ERR_INVALID with the compiler log in ocs_last_error().  ocs_problem_check_source only
- * compiles (no GPU needed). */
+ * compiles (no GPU needed).  Compiled code is kept for the life of the process and, across processes, in a directory
+ * (OCS_JIT_CACHE_DIR, else $XDG_CACHE_HOME/ocs_amd, else $HOME/.cache/ocs_amd; OCS_JIT_CACHE=0: off), keyed by the generated
+ * source, the kernel headers of this build and the compiler version: creating a known plugin costs a file read, not 5-6 s. */
 int ocs_problem_create_from_source(ocs_problem *out, const char *source, int nS, int nC, const double *params,
                                    int nparams, const double *control_bounds, int has_control_char);
 int ocs_problem_check_source(const char *source, int nS, int nC, int nparams, int has_control_char);

@@ -6,6 +6,8 @@
 #include "ocs_handles.hpp"
 
 #include <dlfcn.h>
+#include <sys/stat.h>
+#include <unistd.h>
 
 #include <memory>
 #include <mutex>
@@ -32,6 +34,7 @@ struct Rtc {
   hiprtcResult (*AddNameExpression)(hiprtcProgram, const char*);
   hiprtcResult (*GetLoweredName)(hiprtcProgram, const char*, const char**);
   const char* (*GetErrorString)(hiprtcResult);
+  hiprtcResult (*Version)(int*, int*);
 };
 
 static Rtc* rtc() {
@@ -56,6 +59,7 @@ static Rtc* rtc() {
       L(AddNameExpression, "hiprtcAddNameExpression");
       L(GetLoweredName, "hiprtcGetLoweredName");
       L(GetErrorString, "hiprtcGetErrorString");
+      L(Version, "hiprtcVersion");
 #undef L
       if (r.CreateProgram && r.CompileProgram && r.GetCodeSize && r.GetCode && r.GetProgramLogSize &&
           r.GetProgramLog && r.DestroyProgram && r.AddNameExpression && r.GetLoweredName)
@@ -117,6 +121,101 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep, bool f
   return n;
 }
 
+struct Compiled {
+  std::vector<char> code;
+  std::vector<std::string> lowered;
+};
+
+static unsigned long long fnv1a(const void* data, size_t n, unsigned long long h) {
+  const unsigned char* p = (const unsigned char*)data;
+  for (size_t i = 0; i < n; ++i) {
+    h ^= p[i];
+    h *= 1099511628211ull;
+  }
+  return h;
+}
+static std::string disk_cache_path(const std::string& src, const char* const* hdr, int nhdr, const std::vector<std::string>& names) {
+  const char* off = getenv("OCS_JIT_CACHE");
+  if (off && off[0] == '0') return std::string();
+  std::string dir;
+  if (const char* d = getenv("OCS_JIT_CACHE_DIR")) dir = d;
+  else if (const char* x = getenv("XDG_CACHE_HOME")) dir = std::string(x) + "/ocs_amd";
+  else if (const char* h = getenv("HOME")) dir = std::string(h) + "/.cache/ocs_amd";
+  if (dir.empty()) return std::string();
+  unsigned long long h1 = 1469598103934665603ull, h2 = 0x9E3779B97F4A7C15ull;
+  h1 = fnv1a(src.data(), src.size(), h1);
+  h2 = fnv1a(src.data(), src.size(), h2);
+  for (int k = 0; k < nhdr; ++k) {
+    h1 = fnv1a(hdr[k], strlen(hdr[k]), h1);
+    h2 = fnv1a(hdr[k], strlen(hdr[k]), h2);
+  }
+  for (const std::string& n : names) {
+    h1 = fnv1a(n.data(), n.size() + 1, h1);
+    h2 = fnv1a(n.data(), n.size() + 1, h2);
+  }
+  (void)mkdir(dir.c_str(), 0700);   // (one level; a missing parent simply leaves the cache off)
+  char name[64];
+  snprintf(name, sizeof(name), "/%016llx%016llx.ocsjit", h1, h2);
+  return dir + name;
+}
+// file: "OCSJIT01" | u64 n_names | (u64 len, bytes) x n | u64 code size | code | u64 fnv of everything before
+static bool disk_cache_read(const std::string& path, Compiled& c, int nnames) {
+  FILE* f = fopen(path.c_str(), "rb");
+  if (!f) return false;
+  std::vector<char> buf;
+  char tmp[65536];
+  size_t got;
+  while ((got = fread(tmp, 1, sizeof(tmp), f)) > 0) buf.insert(buf.end(), tmp, tmp + got);
+  fclose(f);
+  if (buf.size() < 8 + 8 + 8 + 8 || memcmp(buf.data(), "OCSJIT01", 8) != 0) return false;
+  unsigned long long want;
+  memcpy(&want, buf.data() + buf.size() - 8, 8);
+  if (fnv1a(buf.data(), buf.size() - 8, 1469598103934665603ull) != want) return false;
+  size_t at = 8;
+  auto u64 = [&](unsigned long long& v) {
+    if (at + 8 > buf.size() - 8) return false;
+    memcpy(&v, buf.data() + at, 8);
+    at += 8;
+    return true;
+  };
+  unsigned long long n = 0;
+  if (!u64(n) || (int)n != nnames) return false;
+  c.lowered.resize(n);
+  for (unsigned long long k = 0; k < n; ++k) {
+    unsigned long long len = 0;
+    if (!u64(len) || at + len > buf.size() - 8) return false;
+    c.lowered[k].assign(buf.data() + at, buf.data() + at + len);
+    at += len;
+  }
+  unsigned long long sz = 0;
+  if (!u64(sz) || at + sz != buf.size() - 8) return false;
+  c.code.assign(buf.data() + at, buf.data() + at + sz);
+  return true;
+}
+static void disk_cache_write(const std::string& path, const Compiled& c) {
+  std::vector<char> buf;
+  auto put = [&](const void* p, size_t n) { buf.insert(buf.end(), (const char*)p, (const char*)p + n); };
+  put("OCSJIT01", 8);
+  unsigned long long n = c.lowered.size();
+  put(&n, 8);
+  for (const std::string& s : c.lowered) {
+    unsigned long long len = s.size();
+    put(&len, 8);
+    put(s.data(), s.size());
+  }
+  unsigned long long sz = c.code.size();
+  put(&sz, 8);
+  put(c.code.data(), c.code.size());
+  const unsigned long long h = fnv1a(buf.data(), buf.size(), 1469598103934665603ull);
+  put(&h, 8);
+  const std::string tmp = path + ".tmp" + std::to_string((long long)getpid());
+  FILE* f = fopen(tmp.c_str(), "wb");
+  if (!f) return;
+  const bool ok = fwrite(buf.data(), 1, buf.size(), f) == buf.size();
+  fclose(f);
+  if (!ok || rename(tmp.c_str(), path.c_str()) != 0) (void)remove(tmp.c_str());   // (atomic: readers see whole files only)
+}
+
 // Compiles the user's source.  `load` = false stops after compilation (usable without a GPU).
 int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool load, UserModule** out,
               std::string& log, bool rowsep, bool ccnox) {
@@ -157,10 +256,6 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   // Compiled code is kept for the life of the process, keyed by the full generated source (the kernel headers are fixed
   // per build of the library): creating the same problem again -- parameter studies, a test suite -- costs a module load
   // instead of 5-6 s of hipRTC.
-  struct Compiled {
-    std::vector<char> code;
-    std::vector<std::string> lowered;
-  };
   // One slot per source; its mutex is held while the source compiles, so concurrent creators of the same problem (the
   // worker threads of ocs_multi_*, one per device) wait for ONE compilation instead of running it N times.
   struct Slot {
@@ -178,6 +273,20 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   }
   std::unique_lock<std::mutex> slot_lk(slot->mu);
   std::shared_ptr<const Compiled> cc = slot->cc;
+  // ... and across processes in a directory (OCS_JIT_CACHE_DIR, else $XDG_CACHE_HOME/ocs_amd, else $HOME/.cache/ocs_amd;
+  // OCS_JIT_CACHE=0 switches it off): one file per (generated source, kernel headers of this build, kernel names), so a script
+  // that creates the same plugin every day pays the 5-6 s of hipRTC once.
+  int rtc_major = 0, rtc_minor = 0;
+  if (r->Version) (void)r->Version(&rtc_major, &rtc_minor);
+  const std::string disk = disk_cache_path(src + "\n// hiprtc " + std::to_string(rtc_major) + "." + std::to_string(rtc_minor) +
+                                               " gfx950 -O3 -ffp-contract=fast", hdr_src, 11, names);
+  if (!cc && !disk.empty()) {
+    auto loaded = std::make_shared<Compiled>();
+    if (disk_cache_read(disk, *loaded, UK_COUNT)) {
+      cc = loaded;
+      slot->cc = cc;
+    }
+  }
   if (!cc) {
     hiprtcProgram prog = nullptr;
     if (r->CreateProgram(&prog, src.c_str(), "ocs_user_problem.hip", 11, hdr_src, hdr_name) != 0) {
@@ -224,6 +333,7 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
     r->DestroyProgram(&prog);
     cc = fresh;
     slot->cc = cc;
+    if (!disk.empty()) disk_cache_write(disk, *fresh);
   }
   slot_lk.unlock();
   UserModule* m = new UserModule();

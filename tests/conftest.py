@@ -8,6 +8,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# compiled plugins of the test suite are cached inside the repository tree (the library's default, ~/.cache/ocs_amd, lies outside)
+os.environ.setdefault("OCS_JIT_CACHE_DIR", os.path.join(ROOT, ".pytest_cache", "ocs_jit"))
+os.makedirs(os.path.join(ROOT, ".pytest_cache"), exist_ok=True)
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

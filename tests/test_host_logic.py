@@ -141,3 +141,33 @@ def test_multi_device_block_arithmetic_matches_the_python_sharding():
                 assert (lo, hi) == (k * base + min(k, rem), k * base + min(k, rem) + base + (1 if k < rem else 0))
                 covered += list(range(lo, hi))
             assert covered == list(range(total))
+
+
+def test_compiled_plugins_are_cached_on_disk(tmp_path, monkeypatch):
+    """ocs_problem_check_source compiles with hipRTC (no GPU needed); the code object lands in OCS_JIT_CACHE_DIR keyed by the
+    generated source, this build's kernel headers and the kernel names, and a second process-level compile is a file read.
+    A damaged file is ignored (checksum) and rewritten; OCS_JIT_CACHE=0 switches the cache off."""
+    import subprocess
+    import sys
+    import time
+    code = (
+        "import sys, time; sys.path.insert(0, %r)\n"
+        "import __graft_entry__ as g; ocs = g.load_package()\n"
+        "from tests.user_problems import PREDPREY_SRC\n"
+        "t0 = time.time(); ocs.UserProblem.check_source(PREDPREY_SRC + '// %%s\\n' %% sys.argv[1], 2, 1, 8); print(time.time() - t0)\n"
+    ) % __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    env = dict(__import__("os").environ, OCS_JIT_CACHE_DIR=str(tmp_path))
+
+    def run(tag, extra=None):
+        e = dict(env, **(extra or {}))
+        out = subprocess.run([sys.executable, "-c", code, tag], env=e, capture_output=True, text=True, check=True)
+        return float(out.stdout.strip().splitlines()[-1])
+    t_first = run("a")
+    files = list(tmp_path.glob("*.ocsjit"))
+    assert len(files) == 1 and files[0].stat().st_size > 10000
+    t_second = run("a")
+    assert t_second < 0.2 * t_first and t_second < 0.5
+    files[0].write_bytes(files[0].read_bytes()[:-100])          # truncated: rejected, compiled again, rewritten
+    assert run("a") > 5 * t_second and files[0].stat().st_size > 10000
+    run("b", {"OCS_JIT_CACHE": "0"})
+    assert len(list(tmp_path.glob("*.ocsjit"))) == 1            # another source with the cache off: nothing new
