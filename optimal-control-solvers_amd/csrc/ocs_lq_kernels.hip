@@ -1615,10 +1615,16 @@ struct LqWorkspace {
   // per-call scratch: cs, ce [C][nS][B]; cj [C][max(1, nC)][B]; off [C + 1][B]
   double *cs = nullptr, *ce = nullptr, *cj = nullptr, *off = nullptr, *zero_u = nullptr, *unit = nullptr;
   size_t cs_cap = 0, ce_cap = 0, cj_cap = 0, off_cap = 0, unit_cap = 0;
+  // state pass under a CONSTANT control (the tail leg of RK4InfiniteIntegrator.m:20-24): the zero-start response of a chunk
+  // does not depend on the trajectory -- one group of 16 identical trajectories, once per (matrices, control vector)
+  double *zc = nullptr, *zz = nullptr;   // [C][nS][16]: the responses; zeros (their start states)
+  size_t zc_cap = 0, zz_cap = 0;
+  const double* zc_key_u = nullptr;
+  bool zc_valid = false;
 };
 void lq_workspace_free(LqWorkspace* w) {
   if (!w) return;
-  for (double* q : {w->MT, w->cs, w->ce, w->cj, w->off, w->zero_u, w->unit})
+  for (double* q : {w->MT, w->cs, w->ce, w->cj, w->off, w->zero_u, w->unit, w->zc, w->zz})
     if (q) (void)hipFree(q);
   delete w;
 }
@@ -1637,10 +1643,11 @@ static int lq_ensure(double*& q, size_t& cap, size_t n) {
 // TRANS = false (state pass):   out[0] = start; out[c+1] = M_c out[c] + add[c], c = 0 .. C-2
 // TRANS = true  (adjoint pass): out[C-1] = start (or zero); out[c-1] = M_c' out[c] + add[c], c = C-1 .. 1;
 //                               last (optional, [nS][B]) = M_0' out[0] + add[0]
+// addB: trajectories in `add` ([C][nS][addB]); addB != B: one column for everybody (column 0)
 template <bool TRANS>
 __global__ __launch_bounds__(256) void k_lq_carry(int nS, int nU, int B, int C, const double* __restrict__ MT,
                                                   const double* __restrict__ start, const double* __restrict__ add,
-                                                  double* out, double* last) {
+                                                  double* out, double* last, int addB) {
   // the chunk matrix and the block's 64 current vectors live in LDS: an iteration is one round of global loads (the
   // next matrix, the next constants) and 32 x 8 multiply-adds per thread from LDS, not 32 dependent global round trips
   __shared__ double Ms[32 * 32];
@@ -1669,7 +1676,7 @@ __global__ __launch_bounds__(256) void k_lq_carry(int nS, int nU, int B, int C, 
 #pragma unroll
     for (int q = 0; q < 8; ++q) {
       const int r = 8 * rg + q;
-      areg[q] = (live && r < nS) ? add[(size_t)c * SB + (size_t)r * B + b] : 0.0;
+      areg[q] = (live && r < nS) ? add[((size_t)c * nS + r) * addB + (addB == B ? b : 0)] : 0.0;
     }
   };
   if (nsteps > 0) fetch(0);
@@ -1800,6 +1807,7 @@ static int lq_chunk_matrices(LqWorkspace* w, const ProblemDesc& p, const GridDes
   a.u = w->zero_u; a.L = L; a.cs = w->unit; a.ce = w->MT;
   k_lq_forward<RT, false, true, 1><<<dim3(nU / 16, C), dim3(64), 0, s>>>(a);
   w->key_ps = p.ps; w->key_version = p.version; w->key_rec = g.REC; w->key_C = C; w->key_N = g.N; w->key_nS = nS;
+  w->zc_valid = false;
   return hip_rc_lq(hipGetLastError());
 }
 
@@ -1824,9 +1832,23 @@ static int lq_forward_chunked(const ProblemDesc& p, const GridDesc& g, int batch
   // pass Z: every chunk from a zero state (cs of the carries is not read: zeros through a memset)
   if (hipMemsetAsync(w->cs, 0, (size_t)C * nS * B * sizeof(double), s) != hipSuccess) return (int)hipErrorUnknown;
   a.cs = w->cs; a.ce = w->ce;
-  if (o.uconst) k_lq_forward<RT, false, true, 1><<<grid, block, 0, s>>>(a);
-  else k_lq_forward<RT, false, false, 1><<<grid, block, 0, s>>>(a);
-  k_lq_carry<false><<<dim3((batch + 63) / 64), dim3(256), 0, s>>>(nS, nU, batch, C, w->MT, x0, w->ce, w->cs, nullptr);
+  if (o.uconst) {
+    // constant control: the zero-start response is one vector per chunk for the whole batch; kept with the matrices
+    if (!w->zc_valid || w->zc_key_u != u) {
+      if ((rc = lq_ensure(w->zc, w->zc_cap, (size_t)C * nS * 16))) return rc;
+      if ((rc = lq_ensure(w->zz, w->zz_cap, (size_t)C * nS * 16))) return rc;
+      if (hipMemsetAsync(w->zz, 0, (size_t)C * nS * 16 * sizeof(double), s) != hipSuccess) return (int)hipErrorUnknown;
+      LQArgs z = a;
+      z.batch = 16; z.x = nullptr; z.J = nullptr; z.Jadd = nullptr; z.cs = w->zz; z.ce = w->zc;
+      k_lq_forward<RT, false, true, 1><<<dim3(1, C), block, 0, s>>>(z);
+      w->zc_key_u = u;
+      w->zc_valid = true;
+    }
+    k_lq_carry<false><<<dim3((batch + 63) / 64), dim3(256), 0, s>>>(nS, nU, batch, C, w->MT, x0, w->zc, w->cs, nullptr, 16);
+  } else {
+    k_lq_forward<RT, false, false, 1><<<grid, block, 0, s>>>(a);
+    k_lq_carry<false><<<dim3((batch + 63) / 64), dim3(256), 0, s>>>(nS, nU, batch, C, w->MT, x0, w->ce, w->cs, nullptr, batch);
+  }
   // pass X
   a.cj = w->cj; a.ce = nullptr;
   if (o.uconst) k_lq_forward<RT, true, true, 2><<<grid, block, 0, s>>>(a);
@@ -1862,7 +1884,7 @@ static int lq_backward_chunked(const ProblemDesc& p, const GridDesc& g, int batc
   // lam(:,1) is wanted, which is the carry below the first chunk
   double* last = nullptr;
   if (o.uconst) last = o.lam0;
-  k_lq_carry<true><<<dim3((batch + 63) / 64), dim3(256), 0, s>>>(nS, nU, batch, C, w->MT, lamT, w->ce, w->cs, last);
+  k_lq_carry<true><<<dim3((batch + 63) / 64), dim3(256), 0, s>>>(nS, nU, batch, C, w->MT, lamT, w->ce, w->cs, last, batch);
   if (o.uconst) {   // the constant objective row of lam(:,1)
     k_lq_set_row<<<dim3((batch + 255) / 256), dim3(256), 0, s>>>(batch, o.lam0 + (size_t)nS * B, lamT ? lamT + (size_t)nS * B : nullptr);
     return hip_rc_lq(hipGetLastError());
@@ -1924,7 +1946,9 @@ int launch_forward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const 
   LQArgs a{};
   a.N = g.N; a.batch = batch; a.nS = p.nS; a.nC = p.nC; a.REC = g.REC; a.ps = p.ps;
   a.x0 = x0; a.u = u; a.x = x; a.J = J; a.Jadd = o.Jadd;
-  if (g.lqws && lq_chunked(batch, g.N, o.mapping))
+  // (a constant control -- the tail leg -- needs no pass Z of its own: the zero-start responses are one vector per chunk for
+  //  the whole batch, so its chunks carry no doubled work and pay as soon as there are two of them)
+  if (g.lqws && lq_chunked(batch, g.N, o.mapping, o.uconst))
     return p.nS <= 16 ? lq_forward_chunked<1>(p, g, batch, x0, u, x, J, o, s) : lq_forward_chunked<2>(p, g, batch, x0, u, x, J, o, s);
   if (p.nS <= 16) {
     run_lq_forward<1>(a, o.uconst, s);
