@@ -574,6 +574,13 @@ def bl5_metric(ocs, dev, batch=8192, nsteps=4000, reps=2, shard=True):
             tr5 = (kb, f"{t5['source']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, k_lq2_backward of both legs; replayed)")
     except Exception:
         pass
+    try:   # ... of the chunked passes of the 1024-trajectory shard (scripts/profile_r04.sh + summarize_r04.py)
+        t5s = json.load(open(os.path.join(ROOT, "profiles", "bl5_shard_traffic_latest.json")))
+        if tr5[0] is None and t5s.get("batch") == nloc and N == 4000:
+            tr5 = (t5s["hbm_bytes_adjoint_kernels_per_pass_pair"],
+                   f"{t5s['source']} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, the k_lq_backward launches of a pass pair; replayed)")
+    except Exception:
+        pass
     return {"value": batch * 2 * N / dt, "unit": "RK4 state+costate steps/s (both legs of RK4InfiniteIntegrator)",
             "batch": batch, "batch_per_gpu": nloc, "n_steps": N, "n_tail_steps": N, "ms_forward": tf * 1e3,
             "ms_adjoint": tb * 1e3, "ms_pass_pair_max_over_ranks": dt * 1e3, "ms_pass_pair_spread": sp5,
@@ -599,7 +606,7 @@ def main():
                     help="trajectories per GPU (weak scaling, default: BASELINE config) / in total (strong scaling)")
     ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
                     help="weak: --batch per GPU (the driver's contract); strong: --batch is the total, split over the GPUs")
-    ap.add_argument("--prewarm", type=float, default=0.4,
+    ap.add_argument("--prewarm", type=float, default=1.0,
                     help="seconds of untimed passes before the W warm-up steps: the clocks of an idle GPU take a few "
                          "hundred ms to come up, and the K timed steps last only a few ms")
     ap.add_argument("--no-cpu-baseline", action="store_true")
