@@ -153,7 +153,8 @@ static std::string disk_cache_path(const std::string& src, const char* const* hd
     h1 = fnv1a(n.data(), n.size() + 1, h1);
     h2 = fnv1a(n.data(), n.size() + 1, h2);
   }
-  (void)mkdir(dir.c_str(), 0700);   // (one level; a missing parent simply leaves the cache off)
+  for (size_t at = 1; at <= dir.size(); ++at)   // mkdir -p (failures simply leave the cache off: fopen fails later)
+    if (at == dir.size() || dir[at] == '/') (void)mkdir(dir.substr(0, at).c_str(), 0700);
   char name[64];
   snprintf(name, sizeof(name), "/%016llx%016llx.ocsjit", h1, h2);
   return dir + name;

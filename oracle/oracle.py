@@ -27,9 +27,10 @@ INTERP_LINEAR, INTERP_LINEAR_NEAREST, INTERP_PREVIOUS, INTERP_PCHIP = 0, 1, 2, 3
 
 def build(force: bool = False) -> str:
     """Compile the oracle with gcc (oracle/Makefile).  Building the checker is not using it."""
-    src = [os.path.join(_HERE, f) for f in ("ocs_oracle.c", "ocs_oracle.h", "Makefile")]
-    stale = (not os.path.exists(_LIB_PATH)) or any(
-        os.path.getmtime(s) > os.path.getmtime(_LIB_PATH) for s in src
+    src = [os.path.join(_HERE, f) for f in ("ocs_oracle.c", "ocs_oracle.h", "Makefile", "ocs_cpu_fast.c")]
+    fast = os.path.join(_HERE, "_build", "libcpufast.so")
+    stale = (not os.path.exists(_LIB_PATH)) or (not os.path.exists(fast)) or any(
+        os.path.getmtime(s) > min(os.path.getmtime(_LIB_PATH), os.path.getmtime(fast)) for s in src
     )
     if force or stale:
         subprocess.run(["make", "-C", _HERE, "-s", "-B" if force else "-s"], check=True)
@@ -485,4 +486,31 @@ def batch_states_adjoints(prob, tspan, x0, u, nthreads=1, want=("x", "J", "lam",
                                        _p(prob.ControlBounds), _p(tspan), tspan.size, batch, _p(x0),
                                        _p(u), _p(out["x"]), _p(out["J"]), _p(out["lam"]),
                                        _p(out["dJdu"]), nthreads)
+    return out
+
+
+_fast = None
+
+
+def fast_logistic_pair(m, c, r, tspan, x0, u, nthreads=1, out=None):
+    """The TUNED CPU implementation of the bench workload (ocs_cpu_fast.c: batch-minor arrays, vector loops over blocks of
+    64 trajectories, stage states recomputed, FMA on) -- bench.py's cpu_baseline beside the literal restatement.
+    x0 [nS][B], u [2N+1][B] (batch-minor) -> dict x, lam [N+1][nS+1][B], dJdu [2N+1][B], J [B]."""
+    global _fast
+    if _fast is None:
+        build()
+        _fast = C.CDLL(os.path.join(_HERE, "_build", "libcpufast.so"))
+        _fast.ocs_fast_logistic_pair.argtypes = [C.c_int, C.c_int, C.c_long, _dp, _dp, C.c_double, C.c_double, _dp, _dp, _dp, _dp,
+                                                 _dp, _dp, C.c_int]
+        _fast.ocs_fast_logistic_pair.restype = None
+    m = np.ascontiguousarray(m, dtype=np.float64).ravel()
+    tspan = np.ascontiguousarray(tspan, dtype=np.float64).ravel()
+    x0, u = np.ascontiguousarray(x0, dtype=np.float64), np.ascontiguousarray(u, dtype=np.float64)
+    nS, B, N = m.size, x0.shape[-1], tspan.size - 1
+    assert nS <= 8 and x0.shape == (nS, B) and u.reshape(2 * N + 1, B).shape == (2 * N + 1, B)
+    if out is None:
+        out = {"x": np.empty((N + 1, nS + 1, B)), "lam": np.empty((N + 1, nS + 1, B)), "dJdu": np.empty((2 * N + 1, B)),
+               "J": np.empty(B)}
+    _fast.ocs_fast_logistic_pair(nS, N, B, _p(tspan), _p(m), float(c), float(r), _p(x0), _p(u), _p(out["x"]), _p(out["J"]),
+                                 _p(out["lam"]), _p(out["dJdu"]), int(nthreads))
     return out

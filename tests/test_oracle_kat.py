@@ -302,3 +302,19 @@ def test_fb_sweep_is_grid_dependent_and_converges_with_the_grid(oracle):
         return [y[0] * (P["m"] - y[0]) - u, np.exp(-P["r"] * t) * (y[0] ** 2 + P["c"] * u * u)]
     s = solve_ivp(rhs, (0.0, 10.0), [1.0, 0.0], method="DOP853", rtol=1e-12, atol=1e-13, max_step=0.05)
     assert abs(s.y[1, -1] - Js[-1]) < 1e-6 * abs(Js[-1])
+
+
+def test_tuned_cpu_baseline_agrees_with_the_restatement(oracle):
+    """oracle/ocs_cpu_fast.c (bench.py's cpu_baseline: the same arithmetic in vector loops over blocks of 64 trajectories,
+    stage states recomputed, FMA contraction on) against the literal restatement of RK4Integrator.m:28-121: round-off."""
+    rng = np.random.default_rng(12)
+    for nS, N, B in ((4, 120, 150), (1, 33, 64), (2, 7, 3)):
+        m = [3.0, 2.5, 2.0, 1.5][:nS]
+        tspan = np.concatenate([[0.0], np.sort(rng.uniform(0, 6, N - 1)), [6.0]])
+        x0, u = rng.uniform(0.8, 1.8, (nS, B)), rng.uniform(0.0, 0.5, (2 * N + 1, B))
+        prob = oracle.LogisticProblem(m, 1.5, 0.05, [[0.0, 1.0]])
+        ref = oracle.batch_states_adjoints(prob, tspan, x0, np.asfortranarray(u[None]), nthreads=2)
+        f = oracle.fast_logistic_pair(m, 1.5, 0.05, tspan, x0, u, nthreads=2)
+        rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))
+        assert rel(f["x"].transpose(1, 0, 2), ref["x"]) < 1e-13 and rel(f["J"], ref["J"]) < 1e-13
+        assert rel(f["lam"].transpose(1, 0, 2), ref["lam"]) < 1e-13 and rel(f["dJdu"][None], ref["dJdu"]) < 1e-13
