@@ -304,3 +304,11 @@ def test_known_answer_decoupled_linear_system(ocs, mapping, nS):
         lr = (1 + z + z**2 / 2 + z**3 / 6 + z**4 / 24) * lr
     assert relerr(lam[:nS, 0, :], lr.astype(np.float64)) < 1e-13 and np.all(lam[nS] == 1.0)
     assert np.all(np.isfinite(dJdu)) and dJdu.shape == u.shape
+
+
+def test_chunked_passes_stress_short(ocs):
+    """tests/stress_lq_chunks.py, 12 random shapes (ragged groups, N down to 2, tail legs, explicit lamT): the requested chunked
+    mapping against the serial one-wave mapping."""
+    from tests.stress_lq_chunks import run
+    failed, worst = run(ocs, 12, seed=7, verbose=False)
+    assert failed == 0 and worst < 1e-11
