@@ -284,7 +284,15 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         auto fetch = [&](int s) OCS_INLINE {
           In v;
           v.c = pw[s * 64];
-          if (!UNI) {
+#ifndef OCS_FOLD_SREC
+#define OCS_FOLD_SREC 0   // tuning builds: 1 = the recursion wave takes the step sizes with scalar loads from the record table
+#endif
+          if (!UNI && OCS_FOLD_SREC) {
+            const uniform_ptr rq = R0 + (size_t)(k * D + s) * RS;
+            v.h = rq[0];
+            v.hh = rq[1];
+            v.h6 = rq[2];
+          } else if (!UNI) {
             v.h = rec[RS * s];
             v.hh = rec[RS * s + 1];
             v.h6 = rec[RS * s + 2];
@@ -293,12 +301,22 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
           }
           return v;
         };
+#ifndef OCS_FOLD_SPF
+#define OCS_FOLD_SPF 1   // steps the recursion wave reads its inputs ahead of their use (tuning builds: 2)
+#endif
         In nxt = fetch(0);
+        In nx2 = nxt;
+        if (OCS_FOLD_SPF == 2) nx2 = fetch(1);
         if constexpr (P::HAS_SHIFT) {
 #pragma unroll
           for (int s = 0; s < D; ++s) {
             const In c = nxt;
-            if (s + 1 < D) nxt = fetch(s + 1);
+            if (OCS_FOLD_SPF == 2) {
+              nxt = nx2;
+              if (s + 2 < D) nx2 = fetch(s + 2);
+            } else if (s + 1 < D) {
+              nxt = fetch(s + 1);
+            }
             __builtin_amdgcn_sched_barrier(0);
             const double cM = c.c.x, cB = c.c.y;
             zw[s * 64] = z;
