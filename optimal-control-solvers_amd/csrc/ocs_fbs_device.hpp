@@ -283,7 +283,14 @@ __global__ __launch_bounds__(64) void k_costate(const CostateArgs a) {
     recp -= rec_stride(NTC);
     return r;
   };
-  constexpr int CH = 8;
+  // steps per prefetched chunk: two chunks of CH (2 NS + 2 NC) doubles are live at a time -- 8 steps for the small problems,
+  // fewer as the state grows (8 steps of a six-state problem are 576 registers: the pass ran out of scratch memory at 3.4 ms
+  // where it takes 1 ms)
+#ifdef OCS_COSTATE_CH
+  constexpr int CH = OCS_COSTATE_CH;
+#else
+  constexpr int CH = NS + NC <= 3 ? 8 : (NS + NC <= 6 ? 4 : (NS + NC <= 10 ? 2 : 1));
+#endif
   const int nch = N / CH;
   for (int i = N - 1; i >= nch * CH; --i) {  // remainder steps at the top, direct loads
     double xA[NS], xM[NS], uA[NC], uM[NC];

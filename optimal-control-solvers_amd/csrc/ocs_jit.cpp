@@ -229,6 +229,18 @@ int jit_build(const char* user_src, int nS, int nC, int npar, bool has_cc, bool 
   src += "#include <hip/hip_runtime.h>\n";
   src += "#define OCS_USER_NS " + std::to_string(nS) + "\n#define OCS_USER_NC " + std::to_string(nC) +
          "\n#define OCS_USER_NPAR " + std::to_string(npar) + "\n";
+  if (const char* defs = getenv("OCS_JIT_DEFINES")) {   // tuning: "NAME=VALUE,NAME=VALUE" ahead of the kernel headers (part of the cache key)
+    std::string d = defs;
+    size_t at = 0;
+    while (at < d.size()) {
+      size_t e = d.find(',', at);
+      if (e == std::string::npos) e = d.size();
+      std::string one = d.substr(at, e - at);
+      const size_t eq = one.find('=');
+      if (!one.empty()) src += "#define " + (eq == std::string::npos ? one : one.substr(0, eq) + " " + one.substr(eq + 1)) + "\n";
+      at = e + 1;
+    }
+  }
   if (has_cc) src += "#define OCS_USER_HAS_CONTROLCHAR 1\n";
   if (rowsep) src += "#define OCS_USER_ROWSEP 1\n";
   const bool fold = rowsep && has_cc && ccnox;
