@@ -146,6 +146,44 @@ __device__ static inline void pchip_run(const PchipTab& T, const double* V, size
   pchip_run_w<R>(T, w, i0, sv, mid);
 }
 
+// The same values one interval at a time: the window of one sample row while a thread walks up its intervals.  va = v(i),
+// sp / sc / sn = secants of intervals i-1, i, i+1, di = slope at node i; step(i) returns the interpolant at local coordinate
+// s of interval i and moves the window to i + 1.  Formulas and operands are pchip_run_w's (reciprocal spacings, pchip_interior1,
+// pchip_end at the two ends of the table): bit-equal results.
+struct PchipSlide {
+  double va, vb, vc, sp, sc, sn, di;
+  __device__ static inline int cl(int k, int hi) { return k < 0 ? 0 : (k > hi ? hi : k); }
+  __device__ inline void init(const PchipTab& T, const double* V, size_t ldB, int i) {
+    const int n = T.n;
+    const double vm = V[(size_t)cl(i - 1, n - 1) * ldB];
+    va = V[(size_t)cl(i, n - 1) * ldB];
+    vb = V[(size_t)cl(i + 1, n - 1) * ldB];
+    vc = V[(size_t)cl(i + 2, n - 1) * ldB];
+    sp = (va - vm) * T.IH[cl(i - 1, n - 2)];
+    sc = (vb - va) * T.IH[cl(i, n - 2)];
+    sn = (vc - vb) * T.IH[cl(i + 1, n - 2)];
+    if (n == 2) di = sc;
+    else if (i == 0) di = pchip_end(T.HN[0], T.HN[1], sc, sn);
+    else if (i >= n - 1) di = 0.0;
+    else di = pchip_interior1(sp, sc, T.W1[i], T.W2[i]);
+  }
+  __device__ inline double step(const PchipTab& T, const double* V, size_t ldB, int i, double s) {   // i < n - 1
+    const int n = T.n, k = i + 1;
+    double dn;
+    if (n == 2) dn = sc;
+    else if (k == n - 1) dn = pchip_end(T.HN[n - 2], T.HN[n - 3], sc, sp);
+    else dn = pchip_interior1(sc, sn, T.W1[k], T.W2[k]);
+    const double ih = T.IH[i], del = sc;
+    const double dzzdx = (del - di) * ih, dzdxdx = (dn - del) * ih;
+    const double c3 = (dzdxdx - dzzdx) * ih, c2 = 2.0 * dzzdx - dzdxdx;
+    const double m = va + s * (di + s * (c2 + s * c3));
+    const double vd = V[(size_t)cl(i + 3, n - 1) * ldB];
+    sp = sc; sc = sn; sn = (vd - vc) * T.IH[cl(i + 2, n - 2)];
+    va = vb; vb = vc; vc = vd; di = dn;
+    return m;
+  }
+};
+
 template <int R>
 __device__ static inline void pchip_mid_run(const PchipTab& T, const double* V, size_t ldB, int i0,
                                             const double* __restrict__ TM, double (&mid)[R]) {
@@ -396,10 +434,78 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
     lb[c] = a.lb[c];
     ub[c] = a.ub[c];
   }
+  const bool ownx = a.xmid == nullptr;  // no midpoint array of x: form those here as well
+  if constexpr (NS > 4) {
+    // Larger state vectors: the run as a ROLLED loop over its intervals with a sliding window per row (PchipSlide) instead of
+    // the unrolled register tables below -- those are 2 NS R doubles and 17 inlined ControlChar evaluations, 170 KB of code
+    // for a six-state problem, and the kernel ran at the speed of the instruction cache (452 us where the data take 100).
+    // Same formulas on the same operands: bit-equal values.
+    double nmax = 0.0, dmax = 1.0;
+    bool any = false;
+    auto emit = [&](int j, const double* x, const double* lam) OCS_INLINE {
+      double tu[NTU], u[NC];
+#pragma unroll
+      for (int k = 0; k < NTU; ++k) tu[k] = a.TU[(size_t)j * NTU + k];
+      P::control_char(tu, x, lam, p, lb, ub, u);
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+        double* dst = a.u + ((size_t)j * NC + c) * B + b;
+        if (a.metric && !(j & 1)) {
+          const double o = *dst;
+          const double n = fabs(u[c] - o), d = a.relTol * fabs(o) + a.absTol;
+          if (n == n && d == d && !(n == 0.0 && d == 0.0)) {
+            if (!any || n * dmax > nmax * d) {
+              nmax = n;
+              dmax = d;
+            }
+            any = true;
+          }
+        }
+        if (a.relax != 1.0) u[c] = __builtin_fma(a.relax, u[c] - *dst, *dst);
+        OCS_FBS_USTORE(u[c], dst);
+      }
+    };
+    PchipSlide sl[NS], sx[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      sl[k].init(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i0);
+      if (ownx) sx[k].init(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i0);
+    }
+    const int iend = i0 + R < N ? i0 + R : N;
+#pragma unroll 1
+    for (int i = i0; i < iend; ++i) {
+      const double sm = a.TM[i] - a.T.TN[i];
+      double x[NS], lam[NS], xm[NS], lm[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        lam[k] = sl[k].va;
+        lm[k] = sl[k].step(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i, sm);
+        if (ownx) {
+          x[k] = sx[k].va;
+          xm[k] = sx[k].step(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i, sm);
+        } else {
+          x[k] = a.x[((size_t)i * a.ldx + k) * B + b];
+          xm[k] = a.xmid[((size_t)i * NS + k) * B + b];
+        }
+      }
+      emit(2 * i, x, lam);
+      emit(2 * i + 1, xm, lm);
+    }
+    if (i0 + R >= N) {  // the run that ends the grid also owns the last node
+      double x[NS], lam[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        x[k] = a.x[((size_t)N * a.ldx + k) * B + b];
+        lam[k] = a.lam[((size_t)N * NS + k) * B + b];
+      }
+      emit(2 * N, x, lam);
+    }
+    if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? nmax / dmax : -1.0;
+    return;
+  }
   double lmid[NS][R];
 #pragma unroll
   for (int k = 0; k < NS; ++k) pchip_mid_run<R>(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i0, a.TM, lmid[k]);
-  const bool ownx = a.xmid == nullptr;  // no midpoint array of x: form those here as well
   double xmr[NS][R];
   if (ownx) {
 #pragma unroll
@@ -539,7 +645,11 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   const size_t B = (size_t)a.batch;
   // Block-uniform fast path: the points of this block lie in consecutive intervals (error / interpolation points
   // as dense as the grid, the default of fb_sweep.m:21-22): one register window per row serves all of them.
-  bool aligned = q0 + kPtsPerThread <= a.nq;
+  // (larger state vectors take the points one by one in a rolled loop: the windows of 2 NS rows and kPtsPerThread inlined
+  // ControlChar evaluations were 87 000 instructions and 784 bytes of scratch per thread for a six-state problem)
+  constexpr bool kWindows = NS <= 4;
+  constexpr int kUnrollPts = kWindows ? kPtsPerThread : 1;
+  bool aligned = kWindows && q0 + kPtsPerThread <= a.nq;
   const int kq0 = a.KQ[q0];
   double sq[kPtsPerThread];
   if (aligned) {
@@ -547,6 +657,19 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
     for (int c = 0; c < kPtsPerThread; ++c) {
       aligned = aligned && a.KQ[q0 + c] == kq0 + c;
       sq[c] = a.SQ[q0 + c];
+    }
+  }
+  PchipSlide sl[NS], sx[NS];   // (larger state vectors: sliding windows in the place of the register tables)
+  bool slide = !kWindows && q0 + kPtsPerThread <= a.nq;
+  if constexpr (!kWindows) {
+#pragma unroll 1
+    for (int c = 1; c < kPtsPerThread && slide; ++c) slide = a.KQ[q0 + c] == kq0 + c;
+    if (slide) {
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        if (P::CC_READS_X) sx[k].init(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0);
+        sl[k].init(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0);
+      }
     }
   }
   double xw[NS][kPtsPerThread], lw[NS][kPtsPerThread];
@@ -558,7 +681,7 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
       pchip_run<kPtsPerThread>(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0, sq, lw[k]);
     }
   }
-#pragma unroll
+#pragma unroll kUnrollPts
   for (int cq = 0; cq < kPtsPerThread; ++cq) {
   const int q = q0 + cq;
   if (q >= a.nq) break;
@@ -569,6 +692,13 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
     for (int k = 0; k < NS; ++k) {
       x[k] = P::CC_READS_X ? xw[k][cq] : 0.0;
       lam[k] = lw[k][cq];
+    }
+  } else if (slide) {
+    const double s = a.SQ[q];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      x[k] = P::CC_READS_X ? sx[k].step(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0 + cq, s) : 0.0;
+      lam[k] = sl[k].step(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0 + cq, s);
     }
   } else {
     const int k0 = a.KQ[q];

@@ -569,6 +569,31 @@ def test_coupled_six_state_three_control_plugin(ocs, oracle):
     assert relerr(prob.gen1.ControlChar(tq, xq, lq), s2["u"][:, :, b]) < 1e-5   # (to the sweep's tolerance: the damped fixed point)
 
 
+def test_six_state_plugin_control_at_points(ocs, oracle):
+    """fb_sweep.m:123 on the six-state plugin: uOpt = ControlChar(interpPts, x(interpPts), lam(interpPts)) with pchip x, lam.  State
+    vectors beyond four rows walk their points with one sliding window per row where the points sit in consecutive intervals
+    (a grid whose nodes are shifted to the right of the uniform ones, nINTERP_PTS = N + 1) and evaluate them one by one
+    otherwise (41 points); error points off the nodes (nERROR_PTS = N + 1 on that grid) take the same kernel inside the
+    loop.  Both against SciPy's pchip of the returned x, lam and the generated NumPy ControlChar."""
+    import importlib
+    from scipy.interpolate import PchipInterpolator
+    from tests.user_problems import ring6_symbolic
+    sym = importlib.import_module("ocs_amd.symbolic")
+    g, f, vals = ring6_symbolic(sym)
+    prob = ocs.make_from_symbolic(g, f, 6, 3, vals, [[0.0, 1.0]] * 3)
+    N, T = 96, 2.0
+    i = np.arange(N + 1)
+    tspan = i * (T / N) + 0.4 * (T / N) * np.sin(np.pi * i / N) ** 2     # t_i in (i h, (i + 1) h) inside, ends on the ends
+    X0 = np.random.default_rng(67).uniform(0.6, 1.8, (6, 70))
+    for nI in (N + 1, 41):
+        s = ocs.fb_sweep_batch(prob, X0, tspan, {"nERROR_PTS": N + 1, "nINTERP_PTS": nI, "nSWEEPS": 4, "uRelax": 0.35})
+        tq = oracle.linspace(0, T, nI)
+        for b in (0, 69):
+            xq = np.vstack([PchipInterpolator(tspan, s["x"][r, :, b])(tq) for r in range(6)])
+            lq = np.vstack([PchipInterpolator(tspan, s["lam"][r, :, b])(tq) for r in range(6)])
+            assert relerr(prob.gen1.ControlChar(tq, xq, lq), s["u"][:, :, b]) < 1e-10, (nI, b)
+
+
 def test_false_declarations_are_refused(ocs):
     """ocs_problem_create_from_source probes the dFdy half of flag bit 2 (control from the costate alone): a plugin whose
     (dF/dy)'v reads u cannot claim it.  Per-trajectory parameters are refused for plugins that tabulate a time coefficient
