@@ -150,35 +150,48 @@ __device__ static inline void pchip_run(const PchipTab& T, const double* V, size
 // sp / sc / sn = secants of intervals i-1, i, i+1, di = slope at node i; step(i) returns the interpolant at local coordinate
 // s of interval i and moves the window to i + 1.  Formulas and operands are pchip_run_w's (reciprocal spacings, pchip_interior1,
 // pchip_end at the two ends of the table): bit-equal results.
+// the tables behind constant-address-space pointers: with plain pointers every table entry read after a store of the kernel
+// is a vector load again (the stores might alias it), waited for at once -- and with it every load that was issued ahead
+struct PchipTabU {
+  int n;
+  uniform_ptr TN, HN, W1, W2, IH;
+  __device__ explicit PchipTabU(const PchipTab& t)
+      : n(t.n), TN(as_uniform(t.TN)), HN(as_uniform(t.HN)), W1(as_uniform(t.W1)), W2(as_uniform(t.W2)), IH(as_uniform(t.IH)) {}
+};
 struct PchipSlide {
-  double va, vb, vc, sp, sc, sn, di;
+  double va, vb, vc, sc, di;   // v(i), v(i+1), v(i+2), secant of interval i, slope at node i
   __device__ static inline int cl(int k, int hi) { return k < 0 ? 0 : (k > hi ? hi : k); }
-  __device__ inline void init(const PchipTab& T, const double* V, size_t ldB, int i) {
+  __device__ inline void init(const PchipTabU& T, const double* V, size_t ldB, int i) {
     const int n = T.n;
     const double vm = V[(size_t)cl(i - 1, n - 1) * ldB];
     va = V[(size_t)cl(i, n - 1) * ldB];
     vb = V[(size_t)cl(i + 1, n - 1) * ldB];
     vc = V[(size_t)cl(i + 2, n - 1) * ldB];
-    sp = (va - vm) * T.IH[cl(i - 1, n - 2)];
+    const double sp = (va - vm) * T.IH[cl(i - 1, n - 2)], sn = (vc - vb) * T.IH[cl(i + 1, n - 2)];
     sc = (vb - va) * T.IH[cl(i, n - 2)];
-    sn = (vc - vb) * T.IH[cl(i + 1, n - 2)];
     if (n == 2) di = sc;
     else if (i == 0) di = pchip_end(T.HN[0], T.HN[1], sc, sn);
     else if (i >= n - 1) di = 0.0;
     else di = pchip_interior1(sp, sc, T.W1[i], T.W2[i]);
   }
-  __device__ inline double step(const PchipTab& T, const double* V, size_t ldB, int i, double s) {   // i < n - 1
+  // vd = v(min(i + 3, n - 1)): loaded by the caller, who can issue the loads of all rows ahead of the arithmetic
+  __device__ static inline double next(const PchipTabU& T, const double* V, size_t ldB, int i) {
+    return V[(size_t)cl(i + 3, T.n - 1) * ldB];
+  }
+  __device__ inline double step(const PchipTabU& T, const double* V, size_t ldB, int i, double s, double vd) {   // i < n - 1
     const int n = T.n, k = i + 1;
+    const double sn = (vc - vb) * T.IH[cl(i + 1, n - 2)];
     double dn;
     if (n == 2) dn = sc;
-    else if (k == n - 1) dn = pchip_end(T.HN[n - 2], T.HN[n - 3], sc, sp);
-    else dn = pchip_interior1(sc, sn, T.W1[k], T.W2[k]);
+    else if (k == n - 1) {   // the last node of the table: the secant of the interval before this one once more (a load)
+      const double sp = (va - V[(size_t)cl(i - 1, n - 1) * ldB]) * T.IH[cl(i - 1, n - 2)];
+      dn = pchip_end(T.HN[n - 2], T.HN[n - 3], sc, sp);
+    } else dn = pchip_interior1(sc, sn, T.W1[k], T.W2[k]);
     const double ih = T.IH[i], del = sc;
     const double dzzdx = (del - di) * ih, dzdxdx = (dn - del) * ih;
     const double c3 = (dzdxdx - dzzdx) * ih, c2 = 2.0 * dzzdx - dzdxdx;
     const double m = va + s * (di + s * (c2 + s * c3));
-    const double vd = V[(size_t)cl(i + 3, n - 1) * ldB];
-    sp = sc; sc = sn; sn = (vd - vc) * T.IH[cl(i + 2, n - 2)];
+    sc = sn;
     va = vb; vb = vc; vc = vd; di = dn;
     return m;
   }
@@ -418,6 +431,118 @@ struct ControlGridArgs {
   double relax;     // the samples become u + relax (uNew - u) (1: the reference's u = uNew, fb_sweep.m:85)
 };
 
+// the control-grid run of larger state vectors (k_control_grid): OWNX = the midpoints of x are formed here too
+template <class P, bool OWNX>
+__device__ static inline void control_grid_slide(const ControlGridArgs& a, int b, int i0, size_t B, const typename P::Par& p,
+                                                 const double* lb, const double* ub) {
+  constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU, R = kPchipRun;
+  const int N = a.N;
+  const PchipTabU TU_(a.T);
+  const uniform_ptr TMu = as_uniform(a.TM), TUu = as_uniform(a.TU);
+  // Larger state vectors: the run as a ROLLED loop over its intervals with a sliding window per row (PchipSlide) instead of
+  // the unrolled register tables below -- those are 2 NS R doubles and 17 inlined ControlChar evaluations, 170 KB of code
+  // for a six-state problem, and the kernel ran at the speed of the instruction cache (452 us where the data take 100).
+  // Same formulas on the same operands: bit-equal values.
+  double nmax = 0.0, dmax = 1.0;
+  bool any = false;
+  auto emit = [&](int j, const double* x, const double* lam, const double* uold) OCS_INLINE {
+    double tu[NTU], u[NC];
+#pragma unroll
+    for (int k = 0; k < NTU; ++k) tu[k] = TUu[(size_t)j * NTU + k];
+    P::control_char(tu, x, lam, p, lb, ub, u);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      double* dst = a.u + ((size_t)j * NC + c) * B + b;
+      const double o = uold[c];
+      if (a.metric && !(j & 1)) {
+        const double n = fabs(u[c] - o), d = a.relTol * fabs(o) + a.absTol;
+        if (n == n && d == d && !(n == 0.0 && d == 0.0)) {
+          if (!any || n * dmax > nmax * d) {
+            nmax = n;
+            dmax = d;
+          }
+          any = true;
+        }
+      }
+      if (a.relax != 1.0) u[c] = __builtin_fma(a.relax, u[c] - o, o);
+      OCS_FBS_USTORE(u[c], dst);
+    }
+  };
+  PchipSlide sl[NS], sx[NS];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) {
+    sl[k].init(TU_, a.lam + (size_t)k * B + b, (size_t)NS * B, i0);
+    if constexpr (OWNX) sx[k].init(TU_, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i0);
+  }
+  const int iend = i0 + R < N ? i0 + R : N;
+  // every load of an interval is issued one interval ahead, at the top of the loop body and ahead of the branches of the
+  // slope formulas (the waves of this kernel spent 80 % of their time waiting for one load after the other)
+  double nl[NS], nx[NS], nm[NS], no[2][NC];
+  auto fetch = [&](int i) OCS_INLINE {
+    const int ic = i < N ? i : N - 1;
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      nl[k] = PchipSlide::next(TU_, a.lam + (size_t)k * B + b, (size_t)NS * B, i);
+      if constexpr (OWNX) {
+        nx[k] = PchipSlide::next(TU_, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i);
+      } else {
+        nx[k] = a.x[((size_t)ic * a.ldx + k) * B + b];
+        nm[k] = a.xmid[((size_t)ic * NS + k) * B + b];
+      }
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {   // the samples that are replaced (the weighted change, the damped update)
+      no[0][c] = a.u[((size_t)(2 * ic) * NC + c) * B + b];
+      no[1][c] = a.u[((size_t)(2 * ic + 1) * NC + c) * B + b];
+    }
+  };
+  fetch(i0);
+#pragma unroll 1
+  for (int i = i0; i < iend; ++i) {
+    double cl_[NS], cx[NS], cm[NS], co[2][NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      cl_[k] = nl[k];
+      cx[k] = nx[k];
+      if constexpr (!OWNX) cm[k] = nm[k];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      co[0][c] = no[0][c];
+      co[1][c] = no[1][c];
+    }
+    fetch(i + 1);
+    const double sm = TMu[i] - TU_.TN[i];
+    double x[NS], lam[NS], xm[NS], lm[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      lam[k] = sl[k].va;
+      lm[k] = sl[k].step(TU_, a.lam + (size_t)k * B + b, (size_t)NS * B, i, sm, cl_[k]);
+      if constexpr (OWNX) {
+        x[k] = sx[k].va;
+        xm[k] = sx[k].step(TU_, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i, sm, cx[k]);
+      } else {
+        x[k] = cx[k];
+        xm[k] = cm[k];
+      }
+    }
+    emit(2 * i, x, lam, co[0]);
+    emit(2 * i + 1, xm, lm, co[1]);
+  }
+  if (i0 + R >= N) {  // the run that ends the grid also owns the last node
+    double x[NS], lam[NS], uo[NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      x[k] = a.x[((size_t)N * a.ldx + k) * B + b];
+      lam[k] = a.lam[((size_t)N * NS + k) * B + b];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) uo[c] = a.u[((size_t)(2 * N) * NC + c) * B + b];
+    emit(2 * N, x, lam, uo);
+  }
+  if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? nmax / dmax : -1.0;
+}
+
 template <class P>
 __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU, R = kPchipRun;
@@ -436,71 +561,8 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   }
   const bool ownx = a.xmid == nullptr;  // no midpoint array of x: form those here as well
   if constexpr (NS > 4) {
-    // Larger state vectors: the run as a ROLLED loop over its intervals with a sliding window per row (PchipSlide) instead of
-    // the unrolled register tables below -- those are 2 NS R doubles and 17 inlined ControlChar evaluations, 170 KB of code
-    // for a six-state problem, and the kernel ran at the speed of the instruction cache (452 us where the data take 100).
-    // Same formulas on the same operands: bit-equal values.
-    double nmax = 0.0, dmax = 1.0;
-    bool any = false;
-    auto emit = [&](int j, const double* x, const double* lam) OCS_INLINE {
-      double tu[NTU], u[NC];
-#pragma unroll
-      for (int k = 0; k < NTU; ++k) tu[k] = a.TU[(size_t)j * NTU + k];
-      P::control_char(tu, x, lam, p, lb, ub, u);
-#pragma unroll
-      for (int c = 0; c < NC; ++c) {
-        double* dst = a.u + ((size_t)j * NC + c) * B + b;
-        if (a.metric && !(j & 1)) {
-          const double o = *dst;
-          const double n = fabs(u[c] - o), d = a.relTol * fabs(o) + a.absTol;
-          if (n == n && d == d && !(n == 0.0 && d == 0.0)) {
-            if (!any || n * dmax > nmax * d) {
-              nmax = n;
-              dmax = d;
-            }
-            any = true;
-          }
-        }
-        if (a.relax != 1.0) u[c] = __builtin_fma(a.relax, u[c] - *dst, *dst);
-        OCS_FBS_USTORE(u[c], dst);
-      }
-    };
-    PchipSlide sl[NS], sx[NS];
-#pragma unroll
-    for (int k = 0; k < NS; ++k) {
-      sl[k].init(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i0);
-      if (ownx) sx[k].init(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i0);
-    }
-    const int iend = i0 + R < N ? i0 + R : N;
-#pragma unroll 1
-    for (int i = i0; i < iend; ++i) {
-      const double sm = a.TM[i] - a.T.TN[i];
-      double x[NS], lam[NS], xm[NS], lm[NS];
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        lam[k] = sl[k].va;
-        lm[k] = sl[k].step(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, i, sm);
-        if (ownx) {
-          x[k] = sx[k].va;
-          xm[k] = sx[k].step(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i, sm);
-        } else {
-          x[k] = a.x[((size_t)i * a.ldx + k) * B + b];
-          xm[k] = a.xmid[((size_t)i * NS + k) * B + b];
-        }
-      }
-      emit(2 * i, x, lam);
-      emit(2 * i + 1, xm, lm);
-    }
-    if (i0 + R >= N) {  // the run that ends the grid also owns the last node
-      double x[NS], lam[NS];
-#pragma unroll
-      for (int k = 0; k < NS; ++k) {
-        x[k] = a.x[((size_t)N * a.ldx + k) * B + b];
-        lam[k] = a.lam[((size_t)N * NS + k) * B + b];
-      }
-      emit(2 * N, x, lam);
-    }
-    if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? nmax / dmax : -1.0;
+    if (ownx) control_grid_slide<P, true>(a, b, i0, B, p, lb, ub);
+    else control_grid_slide<P, false>(a, b, i0, B, p, lb, ub);
     return;
   }
   double lmid[NS][R];
@@ -518,7 +580,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   auto emit = [&](int j, const double* x, const double* lam) OCS_INLINE {  // grid point j
     double tu[NTU], u[NC];
 #pragma unroll
-    for (int k = 0; k < NTU; ++k) tu[k] = a.TU[(size_t)j * NTU + k];
+    for (int k = 0; k < NTU; ++k) tu[k] = as_uniform(a.TU)[(size_t)j * NTU + k];
     P::control_char(tu, x, lam, p, lb, ub, u);
 #pragma unroll
     for (int c = 0; c < NC; ++c) {
@@ -659,6 +721,7 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
       sq[c] = a.SQ[q0 + c];
     }
   }
+  const PchipTabU TU_(a.T);
   PchipSlide sl[NS], sx[NS];   // (larger state vectors: sliding windows in the place of the register tables)
   bool slide = !kWindows && q0 + kPtsPerThread <= a.nq;
   if constexpr (!kWindows) {
@@ -667,8 +730,8 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
     if (slide) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        if (P::CC_READS_X) sx[k].init(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0);
-        sl[k].init(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0);
+        if (P::CC_READS_X) sx[k].init(TU_, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0);
+        sl[k].init(TU_, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0);
       }
     }
   }
@@ -697,8 +760,8 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
     const double s = a.SQ[q];
 #pragma unroll
     for (int k = 0; k < NS; ++k) {
-      x[k] = P::CC_READS_X ? sx[k].step(a.T, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0 + cq, s) : 0.0;
-      lam[k] = sl[k].step(a.T, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0 + cq, s);
+      x[k] = P::CC_READS_X ? sx[k].step(TU_, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0 + cq, s, PchipSlide::next(TU_, a.x + (size_t)k * B + b, (size_t)a.ldx * B, kq0 + cq)) : 0.0;
+      lam[k] = sl[k].step(TU_, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0 + cq, s, PchipSlide::next(TU_, a.lam + (size_t)k * B + b, (size_t)NS * B, kq0 + cq));
     }
   } else {
     const int k0 = a.KQ[q];
@@ -710,7 +773,7 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
     }
   }
 #pragma unroll
-  for (int k = 0; k < NTU; ++k) tu[k] = a.TUQ[(size_t)q * NTU + k];
+  for (int k = 0; k < NTU; ++k) tu[k] = as_uniform(a.TUQ)[(size_t)q * NTU + k];
 #pragma unroll
   for (int c = 0; c < NC; ++c) {
     lb[c] = a.lb[c];

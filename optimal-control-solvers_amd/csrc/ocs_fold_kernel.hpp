@@ -30,8 +30,12 @@
 
 namespace ocs {
 
+#ifndef OCS_FOLD_G1_LDS
+#define OCS_FOLD_G1_LDS 0   // tuning builds: 1 = one-row problems take the interval records through LDS as well
+#endif
 template <int G>
 struct FoldCfg {
+  static constexpr bool PRL = G > 1 || OCS_FOLD_G1_LDS;      // interval records and ControlChar coefficients through LDS
   static constexpr int D = 8, TPW = 64 / G;
   static constexpr int Q = 5;
   static constexpr int NSLOT = Q + 7;
@@ -40,11 +44,11 @@ struct FoldCfg {
   static constexpr int LAM_DBL = D * 64, NLAM = LAM_DBL / 128; // node rows of lam, [node][row][trajectory]
   // pchip interval records and ControlChar coefficients (grid points 2jD .. 2jD+31: a DMA instruction with lanes 0..15
   // only) of a block -- G > 1 only: on G == 1 the control waves read them with scalar loads from the tables
-  static constexpr int PR_DBL = G == 1 ? 0 : D * kPRec;
-  static constexpr int TU_DBL = G == 1 ? 0 : 32;
+  static constexpr int PR_DBL = PRL ? D * kPRec : 0;
+  static constexpr int TU_DBL = PRL ? 32 : 0;
   static constexpr int LOFF = REC_DBL, POFF = LOFF + LAM_DBL, TOFF = POFF + PR_DBL;
   static constexpr int SLOT = TOFF + TU_DBL;
-  static constexpr int LPB = REC_DBL / 128 + NLAM + (G == 1 ? 0 : 2);
+  static constexpr int LPB = REC_DBL / 128 + NLAM + (PRL ? 2 : 0);
   static constexpr int KHEAD = -3;                             // first interval
   static constexpr int U_DBL = 2 * D * TPW;
   static constexpr int NCW = (G == 4) ? 2 : 4;
@@ -52,7 +56,7 @@ struct FoldCfg {
   static constexpr int NPASS = SPW / G > 0 ? SPW / G : 1;
   static constexpr int NUW = D / G;                            // control waves: G steps per wave
   static constexpr int NWAVE = 4 + NCW + NUW;
-  static_assert(REC_DBL == 128 && (G == 1 || PR_DBL == 128) && Q * LPB <= 63, "block shapes");
+  static_assert(REC_DBL == 128 && (!PRL || PR_DBL == 128) && Q * LPB <= 63, "block shapes");
   // wave -> role: the recursion wave shares its SIMD (waves w, w+4, w+8, w+12) with the light roles only
   enum Role { M_ = 0, S_ = 1, P_ = 2, J_ = 3, C_ = 4, U_ = 5 };
 #ifndef OCS_FOLD_ROLEMAP
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
         const int node = j * D + st < N ? j * D + st : N;
         dma16_p2(a.lam + ((size_t)node * G + rr) * B + bw + t2, dst + C_::LOFF + q * 128);
       }
-      if constexpr (G > 1) {
+      if constexpr (C_::PRL) {
         dma16_p2(a.PR + (size_t)jt * C_::PR_DBL + 2 * lane, dst + C_::POFF);
         if (lane < C_::TU_DBL / 2) dma16_p2(a.TU + (size_t)jt * 2 * D + 2 * lane, dst + C_::TOFF);
       }
@@ -188,7 +192,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
       c4 = c4 + 1 == NSLOT ? 0 : c4 + 1;
       double ih0, ih1, W1, W2, svn, tuMn, tuBn, tu0n, hE0 = 0.0, hE1 = 0.0, hE2 = 0.0, ihE = 0.0;
       const bool ends = vs && (js == 0 || js == nb - 1);   // a block with an end of the grid: the three-point formulas
-      if constexpr (G == 1) {
+      if constexpr (!C_::PRL) {
         const int i = vs ? js * D + s : 0;                  // (wave-uniform)
         const uniform_ptr q = PRu + (size_t)i * kPRec;
         ih0 = q[4]; ih1 = q[5]; W1 = q[8]; W2 = q[9]; svn = q[11];
