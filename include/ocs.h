@@ -109,6 +109,10 @@ int ocs_problem_dFdx_times_vec(ocs_problem p, int k, const double *t, const doub
                                const double *v, double *out);
 int ocs_problem_dFdu_times_vec(ocs_problem p, int k, const double *t, const double *y, const double *u,
                                const double *v, double *out);
+/* value = ControlChar(t, x, lam): the Gen-1 problem method (functions/make_from_symbolic.m:33-38) with its clamp to the
+ * control bounds (:111), as fb_sweep.m:96,123 calls it; k columns on the device; host pointers: t [k], x and lam nS x k,
+ * out nC x k.  Registry problems and plugins whose source defines ocs_ControlChar. */
+int ocs_problem_ControlChar(ocs_problem p, int k, const double *t, const double *x, const double *lam, double *out);
 
 /* [xStar, lamStar, uStar, resnorm, residual, exitflag] = compute_equilibrium(prob, xGuess, lamGuess, uGuess, lb, ub, r)
  *                                                                   functions/compute_equilibrium.m:1-34

@@ -42,6 +42,10 @@ classdef GpuUserProblem < OCProblem
          [~, ~, ~, ~, ~, ~, value] = calllib('libocs', 'ocs_problem_dFdu_times_vec', ...
                                              obj.h.Value, k, t, y, u, v, value);
       end
+      function value = ControlChar(obj, t, x, lam)               % make_from_symbolic.m:33-38 (clamped, :111)
+         k = numel(t); value = zeros(size(obj.ControlBounds, 1), k);
+         [~, ~, ~, ~, value] = calllib('libocs', 'ocs_problem_ControlChar', obj.h.Value, k, t, x, lam, value);
+      end
       function delete(obj), calllib('libocs', 'ocs_problem_destroy', obj.h.Value); end
    end
 end

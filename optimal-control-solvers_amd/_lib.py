@@ -53,6 +53,7 @@ _SIG = {
     "ocs_problem_F": (C.c_int, [vp, C.c_int, dp, dp, dp, dp]),
     "ocs_problem_dFdx_times_vec": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp]),
     "ocs_problem_dFdu_times_vec": (C.c_int, [vp, C.c_int, dp, dp, dp, dp, dp]),
+    "ocs_problem_ControlChar": (C.c_int, [vp, C.c_int, dp, dp, dp, dp]),
     "ocs_compute_equilibrium": (C.c_int, [vp, C.c_int, C.c_double, dp, dp, dp, dp, dp, dp, ip]),
     "ocs_compute_equilibrium_dev": (C.c_int, [vp, C.c_int, C.c_double, vp, vp, vp, vp, vp, vp, vp, vp]),
     "ocs_trajectory_status_dev": (C.c_int, [C.c_int, vp, vp, vp]),

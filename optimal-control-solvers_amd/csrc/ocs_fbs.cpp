@@ -313,6 +313,38 @@ static int sweep_problem(ocs_problem_s* p, ocs_problem_s** out) {
   return OCS_OK;
 }
 
+// value = ControlChar(t, x, lam): the Gen-1 problem method of make_from_symbolic.m:33-38 with the clamp of :111, which fb_sweep
+// evaluates on pchip x, lam (fb_sweep.m:96, 123); host pointers, MATLAB shapes: t k, x and lam nS x k, out nC x k.
+int ocs_problem_ControlChar(ocs_problem p, int k, const double* t, const double* x, const double* lam, double* out) {
+  OCS_TRACE("ocs_problem_ControlChar");
+  if (!p || !t || !x || !lam || !out || k < 1) return fail(OCS_ERR_INVALID, "bad argument");
+  OCS_TRY(sweep_problem(p, &p));   // (the LQ problem: its plugin twin)
+  if (p->functor == Functor::User && !(p->user && p->user->has_cc))
+    return fail(OCS_ERR_UNSUPPORTED, "the problem's source defines no ocs_ControlChar");
+  if (p->pmask) return fail(OCS_ERR_UNSUPPORTED, "ControlChar: per-trajectory parameters have no meaning for k free columns");
+  OCS_TRY(upload_problem(p));
+  const int nS = p->nS, nC = p->nC;
+  DevBuf dt, dx, dl, dout;
+  auto body = [&]() -> int {
+    OCS_TRY(dt.ensure(sizeof(double) * k));
+    OCS_TRY(dx.ensure(sizeof(double) * (size_t)nS * k));
+    OCS_TRY(dl.ensure(sizeof(double) * (size_t)nS * k));
+    OCS_TRY(dout.ensure(sizeof(double) * (size_t)nC * k));
+    HIP_TRY(hipMemcpy(dt.p, t, sizeof(double) * k, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dx.p, x, sizeof(double) * (size_t)nS * k, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemcpy(dl.p, lam, sizeof(double) * (size_t)nS * k, hipMemcpyHostToDevice));
+    LAUNCH_TRY(launch_eval(describe(p), 3, k, dt.d(), dx.d(), nullptr, dl.d(), dout.d(), nullptr));
+    HIP_TRY(hipMemcpy(out, dout.p, sizeof(double) * (size_t)nC * k, hipMemcpyDeviceToHost));
+    return OCS_OK;
+  };
+  const int rc = body();
+  dt.release();
+  dx.release();
+  dl.release();
+  dout.release();
+  return rc;
+}
+
 // [x, lam] = compute_x_lam(prob, x0, tspan, u, ...) / [x, lam, J] = compute_x_lam_J(...) on the grid.
 // device: x0 [nS][B], ugrid [2N+1][nC][B] -> xaug [N+1][nAug][B] (states + running objective, the
 // augmented system of compute_x_lam_J.m:6-15), lam [N+1][nS][B], J [B] (may be NULL).

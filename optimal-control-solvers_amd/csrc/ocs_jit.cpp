@@ -441,7 +441,7 @@ int ocs_problem_create_from_source(ocs_problem* out, const char* source, int nS,
   p->version = next_version();
   // Flag bit 2 is a declaration the fold kernels rely on (they pass u = 0 to ocs_row_dFdy and x = 0 to ocs_ControlChar).
   // Its dFdy half is probed here: (dF/dy)' v of the row functions at a few random points must not change with u.
-  // (The ControlChar half -- no dependence on x -- is not probed; symbolic.py derives both from the expressions.)
+  // Its ControlChar half the same way: the clamped ControlChar(t, x, lam) must not change with x.
   if (has_control_char & 4) {
     const int k = 4, nAug = nS + 1;
     std::vector<double> t(k), y((size_t)nAug * k), u1((size_t)nC * k), u2((size_t)nC * k), v((size_t)nAug * k), g1((size_t)nAug * k),
@@ -471,6 +471,22 @@ int ocs_problem_create_from_source(ocs_problem* out, const char* source, int nS,
         ocs_problem_destroy(p);
         return fail(OCS_ERR_INVALID, "flag bit 2 (control from the costate alone) declares that ocs_row_dFdy does not read u, but "
                                      "(dF/dy)' v changes with u (row %d): drop the declaration", (int)(q % nAug));
+      }
+    std::vector<double> x1((size_t)nS * k), x2((size_t)nS * k), lm((size_t)nS * k), c1((size_t)nC * k), c2((size_t)nC * k);
+    for (double& q : x1) q = 0.5 + rnd();
+    for (double& q : x2) q = 1.5 + rnd();
+    for (double& q : lm) q = rnd() - 0.5;
+    rc2 = ocs_problem_ControlChar(p, k, t.data(), x1.data(), lm.data(), c1.data());
+    if (rc2 == OCS_OK) rc2 = ocs_problem_ControlChar(p, k, t.data(), x2.data(), lm.data(), c2.data());
+    if (rc2 != OCS_OK) {
+      ocs_problem_destroy(p);
+      return rc2;
+    }
+    for (size_t q = 0; q < c1.size(); ++q)
+      if (c1[q] != c2[q] && !(std::isnan(c1[q]) && std::isnan(c2[q]))) {
+        ocs_problem_destroy(p);
+        return fail(OCS_ERR_INVALID, "flag bit 2 (control from the costate alone) declares that ocs_ControlChar does not read x, but "
+                                     "its value changes with x (control %d): drop the declaration", (int)(q % nC));
       }
   }
   *out = p;

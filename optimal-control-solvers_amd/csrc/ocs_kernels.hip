@@ -341,16 +341,16 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
 template <class P>
 static void run_eval(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
                      const double* v, double* out, hipStream_t s) {
-  k_eval<P><<<dim3((k + 127) / 128), dim3(128), 0, s>>>(which, k, t, y, u, v, p.ps, out);
+  k_eval<P><<<dim3((k + 127) / 128), dim3(128), 0, s>>>(which, k, t, y, u, v, p.ps, out, p.lb, p.ub);
 }
 int launch_eval(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
                 const double* v, double* out, hipStream_t s) {
   if (p.functor == Functor::User) {
-    const double* ps = p.ps;
-    void* args[] = {&which, &k, &t, &y, &u, &v, &ps, &out};
+    const double *ps = p.ps, *lb = p.lb, *ub = p.ub;
+    void* args[] = {&which, &k, &t, &y, &u, &v, &ps, &out, &lb, &ub};
     return jit_launch(p.user, UK_EVAL, dim3((k + 127) / 128), dim3(128), args, s);
   }
-  if (p.functor == Functor::LQ) return launch_eval_lq(p, which, k, t, y, u, v, out, s);
+  if (p.functor == Functor::LQ) return which == 3 ? -1 : launch_eval_lq(p, which, k, t, y, u, v, out, s);   // (ControlChar: its plugin twin)
   OCS_DISPATCH_LOGISTIC(p.nS, run_eval<P>(p, which, k, t, y, u, v, out, s));
   return hip_rc(hipGetLastError());
 }

@@ -476,13 +476,31 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
 template <class P>
 __global__ void k_eval(int which, int kcols, const double* __restrict__ t, const double* __restrict__ y,
                        const double* __restrict__ u, const double* __restrict__ v,
-                       const double* __restrict__ ps, double* __restrict__ out) {
+                       const double* __restrict__ ps, double* __restrict__ out, const double* __restrict__ lb,
+                       const double* __restrict__ ub) {
   constexpr int NS = P::NS, NC = P::NC, NAUG = P::NAUG;
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= kcols) return;
   const typename P::Par p = P::load(ParamSrc{as_uniform(ps), nullptr, 0u, 0, 0});
   double tc[P::NTC], tu[P::NTU], yy[NS], uu[NC], vv[NAUG];
   P::tcoef(t[j], ps, tc, tu);
+  if (which == 3) {  // ControlChar(t, x, lam) with the clamp (make_from_symbolic.m:33-38, 111): y = x, v = lam, nS rows each
+    double xx[NS], ll[NS], lo[NC], hi[NC], uo[NC];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      xx[k] = y[(size_t)j * NS + k];
+      ll[k] = v[(size_t)j * NS + k];
+    }
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      lo[c] = lb[c];
+      hi[c] = ub[c];
+    }
+    P::control_char(tu, xx, ll, p, lo, hi, uo);
+#pragma unroll
+    for (int c = 0; c < NC; ++c) out[(size_t)j * NC + c] = uo[c];
+    return;
+  }
 #pragma unroll
   for (int k = 0; k < NS; ++k) yy[k] = y[(size_t)j * NAUG + k];
 #pragma unroll

@@ -85,6 +85,15 @@ class OCProblem:
         check(lib.ocs_problem_dFdu_times_vec(self._h, k, _p(t), _p(y), _p(u), _p(v), _p(out)))
         return out
 
+    def ControlChar(self, t, x, lam):
+        """The Gen-1 method of make_from_symbolic.m:33-38 (clamped to ControlBounds, :111) that fb_sweep.m:96,123 evaluates;
+        x, lam: nS x k."""
+        t, k = self._cols(t)
+        x, lam = _f(x, (self.nS, k)), _f(lam, (self.nS, k))
+        out = np.empty((self.nC, k), order="F")
+        check(lib.ocs_problem_ControlChar(self._h, k, _p(t), _p(x), _p(lam), _p(out)))
+        return out
+
 
 class UserProblem(OCProblem):
     """An OCProblem subclass written by the user: the three plugin methods F, dFdx_times_vec and

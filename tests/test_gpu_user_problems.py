@@ -594,6 +594,36 @@ def test_six_state_plugin_control_at_points(ocs, oracle):
             assert relerr(prob.gen1.ControlChar(tq, xq, lq), s["u"][:, :, b]) < 1e-10, (nI, b)
 
 
+def test_control_char_method(ocs, oracle):
+    """ControlChar(t, x, lam) as a problem method (make_from_symbolic.m:33-38 with the clamp of :111; fb_sweep.m:96,123 call
+    it): registry problems against the oracle, the LQ problem through its plugin twin, a generated plugin against the NumPy
+    function SymPy writes, a plugin without ocs_ControlChar refused."""
+    import importlib
+    from tests.user_problems import ring6_symbolic
+    rng = np.random.default_rng(71)
+    k = 37
+    t = rng.uniform(0, 8, k)
+    cases = [(ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]]), oracle.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])),
+             (ocs.LogisticProblem([3.0, 2.5, 2.0, 2.8], 1.5, 0.05, [[0.0, 1.0]]), oracle.LogisticProblem([3.0, 2.5, 2.0, 2.8], 1.5, 0.05, [[0.0, 1.0]]))]
+    nS, nC = 5, 2
+    A = -np.eye(nS) + 0.1 * rng.normal(size=(nS, nS))
+    Bu, q, rd = rng.normal(size=(nS, nC)), rng.uniform(0.5, 1.5, nS), rng.uniform(1, 2, nC)
+    cases.append((ocs.LQProblem(A, Bu, q, rd, 0.05, [[-1.0, 1.0]] * nC), oracle.LQProblem(A, Bu, q, rd, 0.05, [[-1.0, 1.0]] * nC)))
+    for gp, op in cases:
+        x, lam = rng.uniform(0.2, 2.0, (gp.nS, k)), rng.normal(size=(gp.nS, k)) * 0.8
+        got, want = gp.ControlChar(t, x, lam), op.ControlChar(t, x, lam)
+        assert got.shape == (gp.nC, k) and relerr(got, want) < 1e-13
+        lo = -1.0 if gp.nC == 2 else 0.0
+        assert (got == lo).any() or (got == 1.0).any()     # the clamp is active somewhere
+    sym = importlib.import_module("ocs_amd.symbolic")
+    g, f, vals = ring6_symbolic(sym)
+    prob = ocs.make_from_symbolic(g, f, 6, 3, vals, [[0.0, 1.0]] * 3)
+    x, lam = rng.uniform(0.2, 2.0, (6, k)), rng.normal(size=(6, k))
+    assert relerr(prob.ControlChar(t, x, lam), prob.gen1.ControlChar(t, x, lam)) < 1e-13
+    with pytest.raises(ocs.OcsError, match="no ocs_ControlChar"):
+        ocs.UserProblem(PREDPREY_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS).ControlChar(t, x[:2], lam[:2])
+
+
 def test_false_declarations_are_refused(ocs):
     """ocs_problem_create_from_source probes the dFdy half of flag bit 2 (control from the costate alone): a plugin whose
     (dF/dy)'v reads u cannot claim it.  Per-trajectory parameters are refused for plugins that tabulate a time coefficient
@@ -603,6 +633,14 @@ def test_false_declarations_are_refused(ocs):
     ocs.UserProblem(PROPHARVEST_ROWS_CC_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], BOUNDS, **kw)           # without the claim: fine
     with pytest.raises(ocs.OcsError, match="dFdy does not read u"):
         ocs.UserProblem(PROPHARVEST_ROWS_CC_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], BOUNDS, control_from_costate=True, **kw)
+    # ... and the ControlChar half: a ControlChar that reads x (here: scaled by x(1)) cannot claim it either
+    from tests.user_problems import LOGISTIC_ROWS_CC_SRC
+    cc_reads_x = LOGISTIC_ROWS_CC_SRC.replace("s * exp(p[1] * t) / (2 * p[0])", "x[0] * s * exp(p[1] * t) / (2 * p[0])")
+    assert cc_reads_x != LOGISTIC_ROWS_CC_SRC
+    ocs.UserProblem(cc_reads_x, 2, 1, [1.5, 0.05, 3.0, 2.5], BOUNDS, **kw)                         # without the claim: fine
+    with pytest.raises(ocs.OcsError, match="ControlChar does not read x"):
+        ocs.UserProblem(cc_reads_x, 2, 1, [1.5, 0.05, 3.0, 2.5], BOUNDS, control_from_costate=True, **kw)
+    ocs.UserProblem(LOGISTIC_ROWS_CC_SRC, 2, 1, [1.5, 0.05, 3.0, 2.5], BOUNDS, control_from_costate=True, **kw)   # a true claim
     pt = ocs.UserProblem(PREDPREY_TC_SRC, 2, 1, PREDPREY_PARAMS, BOUNDS)
     with pytest.raises(ocs.OcsError, match="tabulated"):
         pt.set_batch_params([4], np.full((1, 8), 2.0))
