@@ -55,8 +55,10 @@ extern "C" {
 
 /* ---- interpolation methods of ocs_interp (griddedInterpolant / vectorInterpolant) ---- */
 #define OCS_INTERP_LINEAR 0
-#define OCS_INTERP_PREVIOUS 2
+#define OCS_INTERP_NEAREST 1  /* the closer sample; halfway: the later one; outside the grid: the end sample */
+#define OCS_INTERP_PREVIOUS 2 /* NaN before the first sample */
 #define OCS_INTERP_PCHIP 3
+#define OCS_INTERP_NEXT 4     /* NaN after the last sample */
 
 typedef struct ocs_problem_s *ocs_problem;
 typedef struct ocs_integrator_s *ocs_integrator;

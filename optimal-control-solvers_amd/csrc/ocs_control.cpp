@@ -230,6 +230,21 @@ static int cstage_out(ocs_control_s* c, const double* src, double* host, int per
   return OCS_OK;
 }
 
+// 'nearest' / 'next' of griddedInterpolant: the index of the sample a query takes (-1: NaN).  Shared with ocs_interp_dev.
+namespace ocs {
+int interp_sample_index(int method, int n, const double* x, double q) {
+  if (q != q) return -1;
+  if (method == OCS_INTERP_NEXT) {
+    if (q > x[n - 1]) return -1;
+    if (q <= x[0]) return 0;
+    const int k = interval_of(n, x, q);   // x[k] <= q < x[k+1] inside, k = n - 2 at q == x[n-1]
+    return q == x[k] ? k : k + 1;
+  }
+  const int k = interval_of(n, x, q);
+  return (q - x[k] < x[k + 1] - q) ? k : k + 1;   // halfway: the later sample (interp1's rule); outside: the end sample
+}
+}  // namespace ocs
+
 extern "C" {
 
 // obj = PWLinearControl(t, nControlPts, nControls)        Control/PWLinearControl.m:13-18
@@ -393,7 +408,8 @@ int ocs_control_compute_nlp_bounds(ocs_control c, const double* bounds, double* 
 // griddedInterpolant the MATLAB shim wraps.  v is nComp x n, out nComp x nq.  Host-side glue.
 int ocs_interp(int method, int nComp, int n, const double* x, const double* v, int nq, const double* tq, double* out) {
   if (!x || !v || !tq || !out || nComp < 1 || n < 2 || nq < 0) return fail(OCS_ERR_INVALID, "bad argument");
-  if (method != OCS_INTERP_LINEAR && method != OCS_INTERP_PREVIOUS && method != OCS_INTERP_PCHIP)
+  if (method != OCS_INTERP_LINEAR && method != OCS_INTERP_PREVIOUS && method != OCS_INTERP_PCHIP &&
+      method != OCS_INTERP_NEAREST && method != OCS_INTERP_NEXT)
     return fail(OCS_ERR_UNSUPPORTED, "unknown interpolation method %d", method);
   std::vector<double> row(n), d(n);
   for (int cidx = 0; cidx < nComp; ++cidx) {
@@ -407,6 +423,9 @@ int ocs_interp(int method, int nComp, int n, const double* x, const double* v, i
           val = NAN;
         else
           val = row[q >= x[n - 1] ? n - 1 : interval_of(n, x, q)];
+      } else if (method == OCS_INTERP_NEAREST || method == OCS_INTERP_NEXT) {
+        const int idx = ocs::interp_sample_index(method, n, x, q);
+        val = idx < 0 ? NAN : row[idx];
       } else {
         const int k = interval_of(n, x, q);
         if (method == OCS_INTERP_LINEAR) {

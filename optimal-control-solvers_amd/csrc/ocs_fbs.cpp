@@ -167,7 +167,8 @@ int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* 
                    double* out, int batch, void* stream) {
   OCS_TRACE("ocs_interp_dev");
   if (!x || !v || !tq || !out || nComp < 1 || n < 2 || nq < 0 || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
-  if (method != OCS_INTERP_LINEAR && method != OCS_INTERP_PREVIOUS && method != OCS_INTERP_PCHIP)
+  if (method != OCS_INTERP_LINEAR && method != OCS_INTERP_PREVIOUS && method != OCS_INTERP_PCHIP &&
+      method != OCS_INTERP_NEAREST && method != OCS_INTERP_NEXT)
     return fail(OCS_ERR_UNSUPPORTED, "unknown interpolation method %d", method);
   for (int i = 0; i + 1 < n; ++i)
     if (!(x[i + 1] > x[i])) return fail(OCS_ERR_INVALID, "sample points must increase strictly");
@@ -200,6 +201,7 @@ int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* 
           hi = mid;
       }
     if (method == OCS_INTERP_PREVIOUS) lo = q < x[0] ? -1 : (q >= x[n - 1] ? n - 1 : lo);
+    if (method == OCS_INTERP_NEAREST || method == OCS_INTERP_NEXT) lo = interp_sample_index(method, n, x, q);
     kq[j] = lo;
     sq[j] = lo >= 0 && lo < n - 1 ? q - x[lo] : 0.0;
   }
@@ -218,7 +220,9 @@ int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* 
   OCS_TRY(upload(KQ, kq.data(), sizeof(int) * nq));
   OCS_TRY(upload(SQ, sq.data(), sizeof(double) * nq));
   const FbsTables tb{n, TN.d(), HN.d(), W1.d(), W2.d(), nullptr, IH.d(), nullptr};
-  LAUNCH_TRY(launch_interp(method, tb, nComp, nq, (const int*)KQ.p, SQ.d(), batch, v, out, s));
+  // ('nearest' and 'next' pick a sample like 'previous' does: the kernel's sample-index mode)
+  const int kmethod = (method == OCS_INTERP_NEAREST || method == OCS_INTERP_NEXT) ? OCS_INTERP_PREVIOUS : method;
+  LAUNCH_TRY(launch_interp(kmethod, tb, nComp, nq, (const int*)KQ.p, SQ.d(), batch, v, out, s));
   HIP_TRY(hipStreamSynchronize(s));
   return OCS_OK;
 }

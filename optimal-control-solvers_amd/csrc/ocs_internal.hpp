@@ -128,6 +128,8 @@ int launch_forward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const 
                       double* x, double* J, const FwdOpts& o, hipStream_t s);
 int launch_backward_lq(const ProblemDesc& p, const GridDesc& g, int batch, const double* xck, const double* u,
                        const double* lamT, double* lam, double* dJdu, const BwdOpts& o, hipStream_t s);
+// 'nearest' / 'next' of griddedInterpolant: index of the sample a query point takes, -1 = NaN (ocs_control.cpp)
+int interp_sample_index(int method, int n, const double* x, double q);
 int launch_eval_lq(const ProblemDesc& p, int which, int k, const double* t, const double* y, const double* u,
                    const double* v, double* out, hipStream_t s);
 

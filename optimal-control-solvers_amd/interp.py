@@ -2,7 +2,7 @@
 
 The solvers return sample arrays; this wrapper turns (grid, samples, method) into the callable
 t (1 x k) -> n x k that the reference's soln.x / soln.lam / soln.u are.  Evaluation is the
-library's host-side ocs_interp (linear / previous / pchip with MATLAB's slope rule)."""
+library's host-side ocs_interp (linear / nearest / previous / next / pchip with MATLAB's slope rule)."""
 from __future__ import annotations
 
 import numpy as np
@@ -10,7 +10,7 @@ import numpy as np
 from ._lib import check, lib
 from .problem import _f, _p
 
-_METHODS = {"linear": 0, "previous": 2, "pchip": 3}
+_METHODS = {"linear": 0, "nearest": 1, "previous": 2, "pchip": 3, "next": 4}
 
 
 def vectorInterpolant(x, v, interpType):

@@ -264,6 +264,10 @@ def test_batched_vector_interpolant_on_device(ocs, oracle, n, nComp, batch, nq):
             assert np.allclose(got[:, :, b].T, ref, rtol=1e-12, atol=1e-13, equal_nan=True), (name, b)
             if name == "previous":
                 assert np.array_equal(got[:, :, b].T, ref, equal_nan=True), (name, b)
+    for name in ("nearest", "next"):      # sample-picking methods: the device picks what the host routine picks
+        got = ocs.vectorInterpolant_dev(x, vd, name)(q).cpu().numpy()
+        for b in sorted({0, batch - 1}):
+            assert np.array_equal(got[:, :, b].T, ocs.vectorInterpolant(x, v[:, :, b].T, name)(q), equal_nan=True), (name, b)
 
 
 def test_cost_row_option(ocs):

@@ -65,6 +65,20 @@ def test_vector_interpolant_matches_oracle(ocs, oracle):
         got = ocs.vectorInterpolant(x, v, name)(q)
         ref = oracle.vector_interp(x, v, m, q)
         assert np.array_equal(got, ref), name
+    # the other sample-picking methods of griddedInterpolant (no caller in the reference; vectorInterpolant.m:4 passes any
+    # method through): SciPy's interp1d inside the grid, the documented rules at ties and outside it
+    from scipy.interpolate import interp1d
+    qi = np.concatenate([x, rng.uniform(x[0], x[-1], 200), 0.5 * (x[:-1] + x[1:])])
+    for name, kind in (("nearest", "nearest-up"), ("next", "next")):
+        gotn = ocs.vectorInterpolant(x, v, name)(qi)
+        refn = interp1d(x, v, kind=kind, axis=1)(qi)
+        ties = np.isin(qi, 0.5 * (x[:-1] + x[1:])) & (name == "nearest")    # (rounded midpoints: either neighbour is "nearest")
+        assert np.array_equal(gotn[:, ~ties], refn[:, ~ties]), name
+    out = np.array([x[0] - 1.0, x[-1] + 1.0])
+    assert np.array_equal(ocs.vectorInterpolant(x, v, "nearest")(out), v[:, [0, -1]])
+    nx = ocs.vectorInterpolant(x, v, "next")(out)
+    assert np.array_equal(nx[:, 0], v[:, 0]) and np.all(np.isnan(nx[:, 1]))
+    assert np.array_equal(ocs.vectorInterpolant([0.0, 1.0, 3.0], [[1.0, 2.0, 4.0]], "nearest")([0.5, 2.0, 0.25]), [[2.0, 4.0, 1.0]])
     one = ocs.vectorInterpolant(x, v[0], "pchip")(q)  # nCOMPONENTS == 1 branch of vectorInterpolant.m:3-4
     assert one.shape == (1, q.size) and np.array_equal(one[0], got[0] * 0 + ocs.vectorInterpolant(x, v[:1], "pchip")(q)[0])
     assert np.array_equal(ocs.heval(ocs.vectorInterpolant(x, v, "linear"), q, [2, 0]),
