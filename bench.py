@@ -655,12 +655,21 @@ def main():
     # collective of the N-rank path (asynchronous objective all-reduce and its drain, barriers, max over ranks, the
     # gathers of the secondary legs) executes on RCCL with world size 1 -- the rehearsal a one-GPU box allows
     use_dist = world > 1 or (os.environ.get("OCS_FORCE_COLLECTIVES") == "1" and "RANK" in os.environ)
+    # OCS_BENCH_REHEARSAL=1: the N-rank code paths on a box with fewer GPUs than ranks -- ranks share the devices there are and
+    # the process group runs on gloo (RCCL refuses two ranks on one device).  The line carries "rehearsal": true; its numbers
+    # mean nothing (the ranks compete for one GPU).
+    rehearsal = os.environ.get("OCS_BENCH_REHEARSAL") == "1" and world > 1
+    ndev = max(torch.cuda.device_count(), 1)
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank if world > 1 else 0)
+        if rehearsal:
+            torch.cuda.set_device(local_rank % ndev)
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", (local_rank % ndev if rehearsal else local_rank) if world > 1 else 0)
     torch.cuda.set_device(dev)
 
     import __graft_entry__ as ge
@@ -775,6 +784,7 @@ def main():
             "unit": "steps/s",
             "n_gpus": world,
             "collectives_executed": bool(use_dist),
+            **({"rehearsal": True} if rehearsal else {}),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
