@@ -462,3 +462,14 @@ def test_adjoint_is_the_gradient_of_the_state_pass_without_the_oracle(ocs, kind,
     scale = np.maximum(np.abs(an), np.abs(J0) * 1e-3 + 1e-6)
     print(kind, mapping, "max relative difference", float(np.max(np.abs(an - fd) / scale)))
     assert np.max(np.abs(an - fd) / scale) < 5e-9   # (observed 2e-11 .. 4e-10: truncation of the difference formula)
+
+
+def test_randomised_pass_pair_stress(ocs, oracle):
+    """tests/stress_rk4.py, 40 random cases: nS 1..4, step counts around the block and chunk sizes of the kernels, whole and ragged
+    tiles, uniform and non-uniform grids, every mapping (forced mappings a shape does not admit are refused, -6), default and
+    explicit lamT -- x, J, lam, dJdu of sampled trajectories against the oracle at 1e-12 (the long run: python tests/stress_rk4.py)."""
+    from tests.stress_rk4 import run
+    lines = []
+    failed, worst = run(ocs, oracle, 40, seed=4, log=lines.append)
+    assert failed == 0, "\n".join(l for l in lines if "FAILED" in l)
+    assert sum("refused" in l for l in lines[:-1]) < 30      # (most cases actually compute)
