@@ -572,3 +572,13 @@ def test_shooting_gradient_is_the_gradient_of_the_objective_without_the_oracle(o
     assert np.max(np.abs(an - fd) / scale) < 5e-9
     if basis == "cheb":
         ctrl.set_fusion("auto")
+
+
+def test_randomised_objective_gradient_stress(ocs, oracle):
+    """tests/stress_nlp.py, 40 random cases of [J, dJdv] = nlpObjective(v) (single_shooting.m:137-150): the three control bases,
+    basis sizes, nS 1..4, step counts and batches around the kernels' block and tile sizes, uniform and non-uniform grids, free
+    initial states, every fusion mode -- sampled candidates against the oracle at 1e-12 (the long run: python tests/stress_nlp.py)."""
+    from tests.stress_nlp import run
+    lines = []
+    failed, worst = run(ocs, oracle, 40, seed=5, log=lines.append)
+    assert failed == 0, "\n".join(l for l in lines if "FAILED" in l)
