@@ -543,7 +543,11 @@ __device__ static inline void control_grid_slide(const ControlGridArgs& a, int b
   if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? nmax / dmax : -1.0;
 }
 
-template <class P>
+// OWNX: larger state vectors (NS > 4) only -- an instance for launches without a midpoint array of x (a.xmid == nullptr) carries
+// a second set of sliding windows (282 registers: one wave per SIMD); it is kept out of the common instance (216: two waves), and
+// not instantiated at all while no costate kernel of these shapes forms the midpoints itself (the launcher refuses).  Up to four
+// states one instance (OWNX = false) serves both cases and looks at a.xmid itself.
+template <class P, bool OWNX = false>
 __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU, R = kPchipRun;
   if (a.gate && *a.gate == 0) return;
@@ -561,8 +565,7 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
   }
   const bool ownx = a.xmid == nullptr;  // no midpoint array of x: form those here as well
   if constexpr (NS > 4) {
-    if (ownx) control_grid_slide<P, true>(a, b, i0, B, p, lb, ub);
-    else control_grid_slide<P, false>(a, b, i0, B, p, lb, ub);
+    control_grid_slide<P, OWNX>(a, b, i0, B, p, lb, ub);   // (the launcher picks the instance by a.xmid)
     return;
   }
   double lmid[NS][R];

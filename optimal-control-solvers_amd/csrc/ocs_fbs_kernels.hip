@@ -93,6 +93,7 @@ int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables
                           status, metric, relTol, absTol, ldb, gate, relax};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
+    if (p.nS > 4 && !xmid) return -1;   // (no costate kernel of these shapes leaves the midpoints of x to this one: OWNX is not instantiated)
     return jit_launch(p.user, UK_CONTROL_GRID, dim3((batch + 255) / 256, (g.N + kPchipRun - 1) / kPchipRun), dim3(256), args, s);
   }
   if (p.functor != Functor::Logistic) return -1;

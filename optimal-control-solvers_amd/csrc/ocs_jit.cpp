@@ -85,7 +85,7 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep, bool f
   n[UK_BWD_UCONST] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, false, false, true>";
   n[UK_EVAL] = "ocs::k_eval<ocs::UserP>";
   n[UK_COSTATE] = "ocs::k_costate<ocs::UserP, 4>";
-  n[UK_CONTROL_GRID] = "ocs::k_control_grid<ocs::UserP>";
+  n[UK_CONTROL_GRID] = "ocs::k_control_grid<ocs::UserP, false>";
   n[UK_CONTROL_PTS] = "ocs::k_control_pts<ocs::UserP>";
   n[UK_TU_AT] = "ocs::k_tu_at<ocs::UserP>";
   n[UK_EQUILIBRIUM] = "ocs::k_equilibrium<ocs::UserP>";
