@@ -114,3 +114,43 @@ def test_forms_the_generator_refuses_or_degrades(ocs, sym):
     ocs.UserProblem.check_source(gen["source"], 3, 2, 1, gen["has_control_char"], False, False)
     with pytest.raises(ValueError):
         sym.generate(sp.Symbol("z") * x[0], [x[0], x[1], x[2]], 3, 2, {"a": 0.5})
+
+
+def reference_symbolic_test2(sym):
+    """The inputs of the reference's tests/symbolic_test2.m:1-11: obj = x^2 + c u^2, rhs = x (m - x) - u, m = .5, c = 4, bounds [0, 1]."""
+    t, x, lam, u, p = sym.symbols(1, 1, ["m", "c"])
+    return x[0] ** 2 + p["c"] * u[0] ** 2, [x[0] * (p["m"] - x[0]) - u[0]], {"m": 0.5, "c": 4.0}, [[0.0, 1.0]]
+
+
+def reference_symbolic_test(sym):
+    """The inputs of the reference's tests/symbolic_test.m:3-14: two states, two controls, obj = x1^2 + x2^2 + u1^2 + u2^2,
+    f = [x1 x2 - u1; u2 x2 + 3] (no parameters; the script sets no bounds: wide ones here)."""
+    t, x, lam, u, p = sym.symbols(2, 2, [])
+    return x[0] ** 2 + x[1] ** 2 + u[0] ** 2 + u[1] ** 2, [x[0] * x[1] - u[0], u[1] * x[1] + 3], {}, [[-50.0, 50.0], [-50.0, 50.0]]
+
+
+def test_reference_symbolic_scripts(ocs, sym):
+    """The two symbolic scripts the reference ships as tests (tests/symbolic_test2.m: make_from_symbolic on the one-state problem;
+    tests/symbolic_test.m: the derivation by hand for two states and two controls): the optimality systems they derive."""
+    g, f, vals, bounds = reference_symbolic_test2(sym)
+    gen = sym.generate(g, f, 1, 1, vals, bounds)
+    t, x, lam, u, p = sym.symbols(1, 1, list(vals))
+    assert gen["form"] == "rows" and gen["has_control_char"] and gen["control_from_costate"]
+    assert sp.simplify(gen["H"] - (x[0] ** 2 + p["c"] * u[0] ** 2 + lam[0] * (x[0] * (p["m"] - x[0]) - u[0]))) == 0   # make_from_symbolic.m:11
+    assert sp.simplify(gen["adjointRHS"][0] + 2 * x[0] + lam[0] * (p["m"] - 2 * x[0])) == 0                              # :14
+    assert sp.simplify(gen["dHdu"][0] - (2 * p["c"] * u[0] - lam[0])) == 0                                               # :17
+    assert sp.simplify(gen["ControlChar"][0] - lam[0] / (2 * p["c"])) == 0                                               # :20-23
+    ocs.UserProblem.check_source(gen["source"], 1, 1, 2, True, True, True)
+    g1 = sym.Gen1Functions(gen)
+    assert np.array_equal(g1.ControlChar(np.zeros(3), np.ones((1, 3)), np.array([[-1.0, 2.0, 20.0]])), [[0.0, 0.25, 1.0]])   # clamp :111
+
+    g, f, vals, bounds = reference_symbolic_test(sym)
+    gen = sym.generate(g, f, 2, 2, vals, bounds)
+    t, x, lam, u, p = sym.symbols(2, 2, [])
+    assert gen["form"] == "vector" and gen["has_control_char"] and not gen["control_from_costate"]
+    # symbolic_test.m:20 g = -gradient(H, x); :23 dHdu; :26-29 uOpt = solve(dHdu, u)
+    assert sp.simplify(gen["adjointRHS"][0] + 2 * x[0] + lam[0] * x[1]) == 0
+    assert sp.simplify(gen["adjointRHS"][1] + 2 * x[1] + lam[0] * x[0] + lam[1] * u[1]) == 0
+    assert sp.simplify(gen["dHdu"][0] - (2 * u[0] - lam[0])) == 0 and sp.simplify(gen["dHdu"][1] - (2 * u[1] + lam[1] * x[1])) == 0
+    assert sp.simplify(gen["ControlChar"][0] - lam[0] / 2) == 0 and sp.simplify(gen["ControlChar"][1] + lam[1] * x[1] / 2) == 0
+    ocs.UserProblem.check_source(gen["source"], 2, 2, 0, True, False, False)
