@@ -141,16 +141,18 @@ static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
   else
     k_forward<P, kChunk, pf_of<P>(), false, false><<<grid, block, 0, s>>>(a);
 }
-// Mapping selection (measured on MI355X, Logistic4, N = 1008; pass pair in us):
-//   batch      lane   row-split   pipeline
-//    1024       644       322        230
-//    4096       672       363        238
-//    8192       731       520        446
-//   16384       821       960        860
-// The wave-specialised pipeline wins while its workgroups (one per 64/nS trajectories, most of a CU's
-// LDS each) fit on the chip in at most two rounds; row-split while the lane mapping would leave most
-// SIMDs idle; beyond that the lane mapping has the fewest instructions per trajectory and the
-// passes turn HBM-bound anyway.
+// Mapping selection, measured on MI355X with the kernels of round 4 (LogisticK, N = 1000; us per pass; scripts/pair_loop.py,
+// profiles/r04_pair_by_batch_mapping.log) by workgroups of the wave-specialised kernels (one per 64/nS trajectories):
+//   workgroups      state pass: lane / pipeline            adjoint pass: lane / scan
+//                   nS = 1      nS = 2      nS = 4          nS = 1        nS = 2       nS = 4
+//      512         256 / 267   209 / 131   297 / 124       351 / 300     296 / 205    439 / 166
+//     1024         434 / 545   285 / 267   342 / 241       647 / 630     429 / 416    466 / 370
+//     2048         837 / 1026  499 / 553   452 / 500      1297 / 1191    791 / 825    639 / 737
+//     4096        1762 / 2046 1004 / 1052  673 / 892      2736 / 2438   1598 / 1628  1172 / 1435
+// The wave-specialised kernels win while the serial chain sets the time -- up to 1024 workgroups (512 with one state, where a
+// lane kernel already has a wave per row) --; beyond that the lane kernels have the fewest instructions per trajectory and both
+// passes are HBM-bound (only the scans with one or two states still match or beat their lane kernels).  Row-split: while the lane mapping would leave most
+// SIMDs idle and the pipeline does not apply.
 // The pipeline kernels take whole blocks of 8 steps.  Other step counts are split: the first 8*floor(N/8) steps
 // go through the pipeline kernel, the remaining (< 8) through the lane kernel, which continues from / hands over
 // the boundary column (running objective, lamT, the k1 half of the boundary column of dJdu), so the result is
@@ -173,16 +175,18 @@ static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested,
   if (requested != MAP_AUTO) return requested;
   const int N1 = plain ? pipeline_steps(p, N, batch, backward) : 0;
   const int tpw = (!backward && forward_is_vector(p)) ? 64 : 64 / p.nS;
-  if (N1 > 0 && (N1 == N || boundary) && batch / tpw <= 512) return MAP_PIPELINE;
+  const int wgmax = (p.nS == 1 || tpw == 64 || backward) ? 512 : 1024;
+  if (N1 > 0 && (N1 == N || boundary) && batch / tpw <= wgmax) return MAP_PIPELINE;
   if (plain && rowsplit_supported(p.functor, p.nS, p.nC) && batch <= 8192) return MAP_ROWSPLIT;
   return MAP_LANE;
 }
 
 // Scan against the serial mappings: the scan does ~2x the arithmetic of a serial adjoint step but has no
 // dependent chain over time; it wins wherever the serial kernels are latency-bound (every batch measured so far).
+// ... wherever the serial kernels are latency-bound: up to 1024 workgroups (table above); with one or two states at every batch
+// (two states beyond 1024 workgroups: within +-5 % of the lane kernel, the sign changes from box to box).
 static bool scan_pays(int nS, int N, int batch) {
-  (void)nS; (void)batch;
-  return N >= 8;
+  return N >= 8 && (nS <= 2 || batch / (64 / nS) <= 1024);
 }
 
 // the wave-specialised state passes on whole horizons (the two-kernel sweep and the fused control update are built on them)
