@@ -49,7 +49,7 @@ bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch) {
     return user_rowsep(p.user) && p.nC == 1 && (p.nS == 1 || p.nS == 2 || p.nS == 4) && N >= 8 && N % 8 == 0 &&
            batch % (64 / p.nS) == 0;
   }
-  return costate_pl_ok(p.functor, p.nS, p.nC, N, batch) && batch / (64 / p.nS) <= 512;
+  return costate_pl_ok(p.functor, p.nS, p.nC, N, batch) && batch / (64 / p.nS) <= fold_wg_limit();
 }
 template <class P>
 static void run_costate(const CostateArgs& a, hipStream_t s) {

@@ -111,6 +111,9 @@ int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const 
                       bool no_cost_row = false, const int* gate = nullptr);
 // whether launch_forward with these shapes runs the one kernel that honours FwdOpts::gate
 bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch);
+// workgroups (of 64/nS trajectories) up to which fb_sweep takes its wave-specialised kernels (the folded two-kernel sweep, the
+// costate kernels that form the midpoints of x); OCS_FOLD_MAX_WG overrides (tuning)
+int fold_wg_limit();
 // ... any state pass the sweep launches (with FwdOpts::frozen set) honours the gate, LQ excepted
 bool forward_gate_any(const ProblemDesc& p);
 bool rowsplit_supported(Functor f, int nS, int nC);

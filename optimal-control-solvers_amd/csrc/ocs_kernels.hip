@@ -190,10 +190,19 @@ static bool scan_pays(int nS, int N, int batch) {
 }
 
 // the wave-specialised state passes on whole horizons (the two-kernel sweep and the fused control update are built on them)
+int fold_wg_limit() {
+  static const int v = [] {
+    const char* e = getenv("OCS_FOLD_MAX_WG");
+    const int n = e ? atoi(e) : 0;
+    return n > 0 ? n : (1 << 30);   // no limit: at 1024-4096 workgroups the folded sweep is 1.3-2.2x faster than the lane sequence
+                                    // (profiles/r04_fbs_by_batch_fold_limit.log; until round 4 the limit was 512)
+  }();
+  return v;
+}
 bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
   if (p.functor == Functor::LQ) return false;
-  return choose_mapping(p, g.N, batch, MAP_AUTO, true, false, true) == MAP_PIPELINE &&
-         pipeline_steps(p, g.N, batch, false) == g.N;
+  const int tpw = forward_is_vector(p) ? 64 : 64 / p.nS;
+  return pipeline_steps(p, g.N, batch, false) == g.N && g.N > 0 && batch / tpw <= fold_wg_limit();
 }
 // any state pass the sweep launches with `frozen` set (pipeline kernels, split passes, the lane kernel): FwdOpts::gate
 bool forward_gate_any(const ProblemDesc& p) { return p.functor != Functor::LQ; }
