@@ -44,7 +44,13 @@ int launch_pchip_mid(const FbsTables& t, int nrows, int ld, int batch, const dou
 // whether launch_costate takes xmid == NULL (with PR) and forms the pchip midpoints of x itself
 bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch) {
   if (p.functor == Functor::User) {
-    if (user_vector(p.user)) return N >= 8 && N % 8 == 0;   // full-vector methods, nS <= 4, nC <= 2: dense step maps
+    if (user_vector(p.user)) {   // full-vector methods, nS <= 4, nC <= 2: dense step maps
+      // at every batch: unlike the adjoint pass of the integrator (ocs_kernels.hip) the sweep's costate scan also spares the
+      // midpoint kernel -- two states, us per sweep with / without it: batch 8192 479 / 627, 32768 1168 / 1276, 65536 2206 / 2338
+      // (profiles/r04_user_vector_pair_by_batch_mapping.log; OCS_COSTATE_VSCAN_MAX sets a limit for A/B runs)
+      static const int vmax = [] { const char* e = getenv("OCS_COSTATE_VSCAN_MAX"); return e ? atoi(e) : 0; }();
+      return N >= 8 && N % 8 == 0 && (vmax <= 0 || batch <= vmax);
+    }
     // problems given as row functions: the scan that reads the control samples
     return user_rowsep(p.user) && p.nC == 1 && (p.nS == 1 || p.nS == 2 || p.nS == 4) && N >= 8 && N % 8 == 0 &&
            batch % (64 / p.nS) == 0;

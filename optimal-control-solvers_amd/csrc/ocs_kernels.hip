@@ -289,7 +289,10 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
   // any other problem with nS <= 4, nC <= 2: the scan with dense step maps, while the lane kernel would leave most of
   // the chip idle (it does (nS + 2) times the arithmetic of a serial step)
   const bool vscan = !scan_ok && plain && g.RECS && vector_problem_ok(p) && Ns >= Ls && (Ns == g.N || lam || o.split_scratch);
-  if (o.mapping == MAP_AUTO && vscan && g.N >= 8 && batch <= 16384 * 3 / (p.nS + 2)) map = MAP_SCAN;
+  // (measured again with round 4's kernels, us per adjoint pass, dense-map scan / lane kernel: nS = 1 at batch 16384 176 / 236,
+  //  32768 365 / 365, 49152 556 / 510; nS = 2 at 16384 271 / 447, 24576 470 / 486, 32768 540 / 496; nS = 4 at 8192 381 / 422,
+  //  16384 415 / 428, 24576 775 / 520 -- profiles/r04_user_vector_pair_by_batch_mapping.log)
+  if (o.mapping == MAP_AUTO && vscan && g.N >= 8 && batch <= 16384 * 6 / (p.nS + 2)) map = MAP_SCAN;
   auto scan_launch = [&](const GridDesc& gg, const double* lT, const double* pend0) {
     return vscan ? launch_backward_vscan(p, gg, batch, xck, u, lT, lam, dJdu, o.lam0, pend0, s)
                  : launch_backward_scan(p, gg, batch, xck, u, lT, lam, dJdu, o.lam0, pend0, s);
