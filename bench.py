@@ -491,8 +491,9 @@ def strong_scaling_readiness(ocs, dev):
 
 
 def bl2_large_batch_metric(ocs, dev, batch=65536, reps=8):
-    """The BL-2 problem in the HBM-bound regime (the lane-per-trajectory mapping at batch 65 536, full output): the
-    figure DESIGN.md quotes for "what the passes reach once the chip is full"."""
+    """The BL-2 problem in the HBM-bound regime (the lane-per-trajectory mapping at batch 65 536, full output; its adjoint kernel
+    reads one checkpoint in four and re-integrates the others): the figure DESIGN.md quotes for "what the passes reach once the
+    chip is full".  `achieved` counts the algorithmic 168 B per trajectory-step (SURVEY 8(d)), `traffic` what the counters saw."""
     tspan, x0_h, u_h = make_inputs(batch, dev, 20260409)
     prob = ocs.LogisticProblem(M, C_PAR, R_PAR, [[0.0, 1.0]])
     integ = ocs.RK4Integrator(tspan).set_mapping("lane")
@@ -510,7 +511,7 @@ def bl2_large_batch_metric(ocs, dev, batch=65536, reps=8):
     tr = _replayed_variant_traffic(f"lane_{NS}_{batch}")
     return {"value": batch * NSTEPS / dt, "unit": "RK4 state+costate steps/s", "batch": batch, "mapping": "lane",
             "ms_per_pass_pair": dt * 1e3, "ms_per_pass_pair_spread": sp,
-            "roofline": {"bound": "hbm", "kernel": "k_forward + k_backward (lane per trajectory), pass pair",
+            "roofline": {"bound": "hbm", "kernel": "k_forward + k_backward<XRC> (lane per trajectory; the adjoint re-integrates 3 of 4 checkpoints), pass pair",
                          "achieved": nbytes / dt / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": nbytes / dt / 1e9 / HBM_PEAK_GBPS, "traffic": tr[0], "traffic_source": tr[1]}}
 

@@ -151,7 +151,7 @@ static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
 //     4096        1762 / 2046 1004 / 1052  673 / 892      2736 / 2438   1598 / 1628  1172 / 1435
 // The wave-specialised kernels win while the serial chain sets the time -- up to 1024 workgroups (512 with one state, where a
 // lane kernel already has a wave per row) --; beyond that the lane kernels have the fewest instructions per trajectory and both
-// passes are HBM-bound (only the scans with one or two states still match or beat their lane kernels).  Row-split: while the lane mapping would leave most
+// passes are HBM-bound (only the one-state scan still matches its lane kernel).  Row-split: while the lane mapping would leave most
 // SIMDs idle and the pipeline does not apply.
 // The pipeline kernels take whole blocks of 8 steps.  Other step counts are split: the first 8*floor(N/8) steps
 // go through the pipeline kernel, the remaining (< 8) through the lane kernel, which continues from / hands over
@@ -183,10 +183,12 @@ static int choose_mapping(const ProblemDesc& p, int N, int batch, int requested,
 
 // Scan against the serial mappings: the scan does ~2x the arithmetic of a serial adjoint step but has no
 // dependent chain over time; it wins wherever the serial kernels are latency-bound (every batch measured so far).
-// ... wherever the serial kernels are latency-bound: up to 1024 workgroups (table above); with one or two states at every batch
-// (two states beyond 1024 workgroups: within +-5 % of the lane kernel, the sign changes from box to box).
+// ... wherever the serial kernels are latency-bound: up to 1024 workgroups (table above); with one state at every batch.
+// Beyond that the lane kernel re-integrates three of four checkpoints (k_backward<..., XRC>, from batch 32768) and wins with two
+// and four states: adjoint pass at batch 65536, scan / lane / lane with re-integration: nS = 4 1435 / 1185 / 903 us, nS = 2
+// 825 / 811 / 720; nS = 1 at 131072: 1191 / 1327 / 1167 (level: the scan stays).
 static bool scan_pays(int nS, int N, int batch) {
-  return N >= 8 && (nS <= 2 || batch / (64 / nS) <= 1024);
+  return N >= 8 && (nS == 1 || batch / (64 / nS) <= 1024);
 }
 
 // the wave-specialised state passes on whole horizons (the two-kernel sweep and the fused control update are built on them)
@@ -261,9 +263,28 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
   return hip_rc(hipGetLastError());
 }
 
+// the lane adjoint kernel with checkpoint re-integration (k_backward<..., XRC>): where the launch fills the chip and the pass is
+// HBM-bound (OCS_LANE_XRC_MIN: batch from which it is taken; 0 = never)
+static int lane_xrc_min_batch() {
+  static const int v = [] {
+    const char* e = getenv("OCS_LANE_XRC_MIN");
+    return e ? atoi(e) : 32768;
+  }();
+  return v;
+}
 template <class P>
 static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
   const dim3 grid((a.batch + 63) / 64), block(64);
+  const int xmin = lane_xrc_min_batch();
+  if (!uconst && xmin > 0 && a.batch >= xmin && a.N >= kChunk) {
+    if (a.lam && a.dJdu)
+      k_backward<P, kChunk, kChunk, true, true, false, true><<<grid, block, 0, s>>>(a);
+    else if (a.lam)
+      k_backward<P, kChunk, kChunk, true, false, false, true><<<grid, block, 0, s>>>(a);
+    else
+      k_backward<P, kChunk, kChunk, false, true, false, true><<<grid, block, 0, s>>>(a);
+    return;
+  }
   if (uconst)
     k_backward<P, kChunk, pf_of<P>(), false, false, true><<<grid, block, 0, s>>>(a);
   else if (a.lam && a.dJdu)

@@ -248,8 +248,13 @@ struct BwdArgs {
   double* lam0;         // optional [nAug][B]: lam(:,1) only (RK4InfiniteIntegrator.m:29, single_shooting.m:149)
 };
 
-template <class P, int CH, int PF, bool OUT_LAM, bool OUT_DJDU, bool UCONST>
+// XRC (checkpoint re-integration, as in the scan kernel, ocs_scan_kernel.hpp): of the CH checkpoints of a chunk only the first is
+// read; the others are integrated forward from it with the state pass's own operations (the control samples and step records of
+// the chunk are at hand anyway).  +3 evaluations of the state rows per step against 3/4 of the checkpoint reads: for launches
+// that are HBM-bound (the chip full of waves), not for the latency-bound ones.  Needs PF >= CH (the ring holds the chunk's records).
+template <class P, int CH, int PF, bool OUT_LAM, bool OUT_DJDU, bool UCONST, bool XRC = false>
 __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
+  static_assert(!XRC || (PF >= CH && !UCONST), "re-integration: the record ring must hold a chunk");
   constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC, NAUG = P::NAUG;
   using Rec = StepRec<NTC>;
   const int b0 = blockIdx.x * 64 + threadIdx.x;
@@ -416,6 +421,10 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
   auto load_chunk = [&](double (&xd)[CH][NS], double (&ud)[2 * CH][NC]) OCS_INLINE {
 #pragma unroll
     for (int s = CH - 1; s >= 0; --s) {
+      if (XRC && s > 0) {   // integrated from checkpoint 0 of the chunk in run_chunk
+        xp -= (size_t)(NS + 1) * B;
+        continue;
+      }
       xp -= B;  // cost row skipped
 #pragma unroll
       for (int k = NS - 1; k >= 0; --k) {
@@ -431,7 +440,34 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
         ud[s][cc] = *up;
       }
   };
-  auto run_chunk = [&](const double (&xs)[CH][NS], const double (&us)[2 * CH][NC]) OCS_INLINE {
+  auto run_chunk = [&](const double (&xs0)[CH][NS], const double (&us)[2 * CH][NC]) OCS_INLINE {
+    double xs[CH][NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) xs[0][k] = xs0[0][k];
+#pragma unroll
+    for (int s = 1; s < CH; ++s) {
+      if (XRC) {   // x(:, i0 + s) from x(:, i0 + s - 1): compute_states :39-51 on the state rows, the state pass's operations
+        const Rec& r = rq[CH - s];   // the ring holds the records of steps i0 + CH - 1 (rq[0]) .. i0 (rq[CH - 1])
+        const double *y = xs[s - 1], *uA = us[2 * s - 2], *uM = us[2 * s - 1], *uB = us[2 * s];
+        double F1[NS], F2[NS], F3[NS], F4[NS], Y[NS];
+        P::Fx(r.tcA, y, uA, p, F1);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) Y[k] = __builtin_fma(r.hh, F1[k], y[k]);
+        P::Fx(r.tcM, Y, uM, p, F2);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) Y[k] = __builtin_fma(r.hh, F2[k], y[k]);
+        P::Fx(r.tcM, Y, uM, p, F3);
+#pragma unroll
+        for (int k = 0; k < NS; ++k) Y[k] = __builtin_fma(r.h, F3[k], y[k]);
+        P::Fx(r.tcB, Y, uB, p, F4);
+#pragma unroll
+        for (int k = 0; k < NS; ++k)
+          xs[s][k] = __builtin_fma(r.h6, __builtin_fma(2.0, F3[k], __builtin_fma(2.0, F2[k], F1[k])) + F4[k], y[k]);
+      } else {
+#pragma unroll
+        for (int k = 0; k < NS; ++k) xs[s][k] = xs0[s][k];
+      }
+    }
 #pragma unroll
     for (int s = CH - 1; s >= 0; --s) {
       const Rec cur = next_rec();
