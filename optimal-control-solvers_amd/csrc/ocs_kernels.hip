@@ -131,11 +131,22 @@ constexpr int kChunk = 4;
 template <class P>
 constexpr int pf_of() { return P::NS <= 2 ? 4 : 3; }
 
+// the lane adjoint kernel with checkpoint re-integration (k_backward<..., XRC>): where the launch fills the chip and the pass is
+// HBM-bound (OCS_LANE_XRC_MIN: batch from which it is taken; 0 = never)
+static int lane_xrc_min_batch() {
+  static const int v = [] {
+    const char* e = getenv("OCS_LANE_XRC_MIN");
+    return e ? atoi(e) : 32768;
+  }();
+  return v;
+}
 template <class P>
 static void run_forward(const FwdArgs& a, bool uconst, hipStream_t s) {
   const dim3 grid((a.batch + 63) / 64), block(64);
   if (uconst)
     k_forward<P, kChunk, pf_of<P>(), true, true><<<grid, block, 0, s>>>(a);
+  else if (a.x && lane_xrc_min_batch() > 0 && a.batch >= lane_xrc_min_batch())
+    k_forward<P, kChunk, pf_of<P>(), true, false, true><<<grid, block, 0, s>>>(a);   // (non-temporal stores of x)
   else if (a.x)
     k_forward<P, kChunk, pf_of<P>(), true, false><<<grid, block, 0, s>>>(a);
   else
@@ -263,15 +274,6 @@ int launch_forward(const ProblemDesc& p, const GridDesc& g, int batch, const dou
   return hip_rc(hipGetLastError());
 }
 
-// the lane adjoint kernel with checkpoint re-integration (k_backward<..., XRC>): where the launch fills the chip and the pass is
-// HBM-bound (OCS_LANE_XRC_MIN: batch from which it is taken; 0 = never)
-static int lane_xrc_min_batch() {
-  static const int v = [] {
-    const char* e = getenv("OCS_LANE_XRC_MIN");
-    return e ? atoi(e) : 32768;
-  }();
-  return v;
-}
 template <class P>
 static void run_backward(const BwdArgs& a, bool uconst, hipStream_t s) {
   const dim3 grid((a.batch + 63) / 64), block(64);

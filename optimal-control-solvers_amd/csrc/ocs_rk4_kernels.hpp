@@ -73,7 +73,15 @@ struct FwdArgs {
 // Lanes past the end of the batch are clamped onto the last trajectory: they recompute it and
 // store the same values to the same addresses, which keeps the step body free of exec-mask
 // branches (one basic block per chunk, so the scheduler can hoist the prefetch loads).
-template <class P, int CH, int PF, bool OUT_X, bool UCONST>
+// stores of the per-step outputs (x, lam, dJdu): non-temporal in the instances that serve launches beyond the memory-side cache
+// (NT: batch >= 32768, where the next pass cannot find them there anyway; pair at batch 65536 1704 -> 1652 us)
+template <bool NT>
+__device__ static inline void lane_store(double* ptr, double val) {
+  if (NT) __builtin_nontemporal_store(val, ptr);
+  else *ptr = val;
+}
+#define OCS_LANE_ST(ptr, val) lane_store<NT>((ptr), (val))
+template <class P, int CH, int PF, bool OUT_X, bool UCONST, bool NT = false>
 __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
   if (a.gate && *a.gate == 0) return;
   constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC;
@@ -142,10 +150,10 @@ __global__ __launch_bounds__(64) void k_forward(const FwdArgs a) {
     if (OUT_X) {
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
-        *xo = y[k];
+        OCS_LANE_ST(xo, y[k]);
         xo += xstep;
       }
-      *xo = yc;
+      OCS_LANE_ST(xo, yc);
       xo += xstep;
     }
   };
@@ -254,6 +262,7 @@ struct BwdArgs {
 // that are HBM-bound (the chip full of waves), not for the latency-bound ones.  Needs PF >= CH (the ring holds the chunk's records).
 template <class P, int CH, int PF, bool OUT_LAM, bool OUT_DJDU, bool UCONST, bool XRC = false>
 __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
+  constexpr bool NT = XRC;   // (the same launches: HBM-bound, outputs larger than the memory-side cache)
   static_assert(!XRC || (PF >= CH && !UCONST), "re-integration: the record ring must hold a chunk");
   constexpr int NS = P::NS, NC = P::NC, NTC = P::NTC, NAUG = P::NAUG;
   using Rec = StepRec<NTC>;
@@ -347,12 +356,12 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
 #pragma unroll
       for (int c = NC - 1; c >= 0; --c) {
         dp -= B;
-        *dp = pend[c] + d4[c];  // column 2i+2  :112-116 (:119-120 at i = N-1)
+        OCS_LANE_ST(dp, pend[c] + d4[c]);  // column 2i+2  :112-116 (:119-120 at i = N-1)
       }
 #pragma unroll
       for (int c = NC - 1; c >= 0; --c) {
         dp -= B;
-        *dp = d2[c] + d3[c];    // column 2i+1  :105-109
+        OCS_LANE_ST(dp, d2[c] + d3[c]);    // column 2i+1  :105-109
       }
       P::dFduT(r.tcA, xi, uA, p, k1, pend);
     }
@@ -360,11 +369,11 @@ __global__ __launch_bounds__(64) void k_backward(const BwdArgs a) {
     for (int k = 0; k < NS; ++k) lam[k] = (((lam[k] + g1[k]) + g2[k]) + g3[k]) + g0[k];  // :86-88
     if (OUT_LAM) {
       lo -= B;
-      *lo = lamc;
+      OCS_LANE_ST(lo, lamc);
 #pragma unroll
       for (int k = NS - 1; k >= 0; --k) {
         lo -= B;
-        *lo = lam[k];
+        OCS_LANE_ST(lo, lam[k]);
       }
     }
   };
