@@ -1324,7 +1324,10 @@ int launch_costate_plx(const ProblemDesc& p, const GridDesc& g, int batch, const
                        const int* frozen, double* dump, double* lam, int ld, hipStream_t s, const int* gate) {
   if (!costate_pl_ok(p.functor, p.nS, p.nC, g.N, batch) || (frozen && !dump) || !PR) return -1;
   if (ld == 0 && costate_scan_ok(p, g, batch)) return launch_costate_scan(p, g, batch, x, ldx, PR, frozen, lam, s, gate);
-  const CostateXArgs a{CostateArgsPL{g.N, batch, ld, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, frozen, dump, lam}, PR, gate};
+  CostateXArgs a{};   // (the MET fields stay zero: the plain costate pass)
+  a.c = CostateArgsPL{g.N, batch, ld, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, frozen, dump, lam};
+  a.PR = PR;
+  a.gate = gate;
   if (p.nS == 1)
     run_costate_plx<LogisticK<1>>(a, s);
   else if (p.nS == 2)
