@@ -81,6 +81,7 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep, bool f
   n[UK_FWD_UCONST] = "ocs::k_forward<ocs::UserP, " + ch + ", 4, true, true>";
   n[UK_BWD_LAM_DJDU] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, true, true, false>";
   n[UK_BWD_LAM] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, true, false, false>";
+  if (user_chunk(nS) == 4) n[UK_BWD_LAM_DJDU_XRC] = "ocs::k_backward<ocs::UserP, 4, 4, true, true, false, true>";
   n[UK_BWD_DJDU] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, false, true, false>";
   n[UK_BWD_UCONST] = "ocs::k_backward<ocs::UserP, " + ch + ", 4, false, false, true>";
   n[UK_EVAL] = "ocs::k_eval<ocs::UserP>";

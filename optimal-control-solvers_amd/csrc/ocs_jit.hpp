@@ -32,6 +32,8 @@ enum UserKernel : int {
   UK_COSTATE_SCAN_U,
   // full-vector problems with nS <= 4, nC <= 2: the costate pass of the sweep as a scan with dense step maps
   UK_COSTATE_VSCAN,
+  // nS <= 4: the lane adjoint kernel with checkpoint re-integration and non-temporal stores (HBM-bound launches, full output)
+  UK_BWD_LAM_DJDU_XRC,
   UK_COUNT
 };
 

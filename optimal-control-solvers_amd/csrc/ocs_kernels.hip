@@ -370,7 +370,9 @@ int launch_backward(const ProblemDesc& p, const GridDesc& g, int batch, const do
   const BwdArgs a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, xck, u, lamT, lam, dJdu, o.lam0};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
-    const int kid = o.uconst ? UK_BWD_UCONST : (lam && dJdu ? UK_BWD_LAM_DJDU : (lam ? UK_BWD_LAM : UK_BWD_DJDU));
+    int kid = o.uconst ? UK_BWD_UCONST : (lam && dJdu ? UK_BWD_LAM_DJDU : (lam ? UK_BWD_LAM : UK_BWD_DJDU));
+    const int xmin = lane_xrc_min_batch();   // (as for the registry problems: re-integration where the launch is HBM-bound)
+    if (kid == UK_BWD_LAM_DJDU && xmin > 0 && batch >= xmin && g.N >= 4 && p.nS <= 4) kid = UK_BWD_LAM_DJDU_XRC;
     return jit_launch(p.user, kid, dim3((batch + 63) / 64), dim3(64), args, s);
   }
   OCS_DISPATCH_LOGISTIC(p.nS, run_backward<P>(a, o.uconst, s));
