@@ -451,3 +451,30 @@ def test_fb_sweep_solution_properties_without_the_oracle(ocs, nS, batch):
         ug[0, :, j] = np.clip(lam_g.sum(axis=0) * np.exp(r * tg) / (2 * c), 0.0, 1.0)
     x2, lam2 = ocs.compute_x_lam(prob, x0[:, bsel], tspan, ug, integrator=ocs.RK4Integrator(tspan))
     assert np.max(np.abs(x2 - s["x"][:, :, bsel])) < 2e-2 and np.max(np.abs(lam2 - s["lam"][:, :, bsel])) < 2e-2
+
+
+@pytest.mark.parametrize("nS,batch", [(1, 40000), (2, 24000), (4, 10000)])
+def test_two_kernel_sweep_beyond_512_workgroups(ocs, oracle, nS, batch):
+    """Until round 4 the folded sweep stopped at 512 workgroups of 64/nS instances; beyond it the loop ran the lane kernels.  The
+    fold at 625-750 workgroups: same sweep counts and solution as the kernel-by-kernel sequence (fused_update_off = 1) for every
+    instance, and the oracle on sampled instances."""
+    rng = np.random.default_rng(batch)
+    N = 64
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    tspan = oracle.linspace(0, 1.0, N + 1)
+    x0 = rng.uniform(0.8, 2.0, (nS, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    base = {"nERROR_PTS": N + 1, "nINTERP_PTS": 17, "nSWEEPS": 40}
+    ga, gb = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
+    ra = ocs.fb_sweep_batch(prob, x0, tspan, dict(base), integrator=ga)
+    rb = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=1), integrator=gb)
+    assert ocs.fb_sweep_path(ga) == 4 and ocs.fb_sweep_path(gb) == 1 and batch * nS // 64 > 512
+    assert np.array_equal(ra["sweeps"], rb["sweeps"]) and ra["sweeps"].min() > 0
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rb[key]) < 1e-12, key
+    for b in (0, batch // 3, batch - 1):
+        ref = oracle.fb_sweep(oracle.LogisticProblem(m, cs[b], P["r"], BOUNDS), x0[:, b], tspan, base)
+        assert ra["sweeps"][b] == ref["_sweeps"] and abs(ra["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
+        assert relerr(ra["x"][:, :, b], ref["x"]) < RTOL and relerr(ra["u"][:, :, b], ref["u"]) < RTOL
