@@ -327,7 +327,7 @@ int ocs_control_compute_u_dev(ocs_control c, int batch, const double* v, double*
   OCS_TRACE("ocs_control_compute_u_dev");
   if (!c || !v || !u || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_control(c));
-  if (c->dense && batch >= 16384) {  // below that the time-parallel sparse kernel fills the chip better
+  if (c->dense) {  // (time-parallel since round 4: at every batch)
     LAUNCH_TRY(launch_basis_dense(true, c->nBasis, c->nT, c->nC, batch, c->d_BT.d(), v, u, (hipStream_t)stream));
     return OCS_OK;
   }
@@ -339,7 +339,7 @@ int ocs_control_compute_u_dev(ocs_control c, int batch, const double* v, double*
 int ocs_control_compute_dJdv_dev(ocs_control c, int batch, const double* dJdu, double* dJdv, void* stream) {
   if (!c || !dJdu || !dJdv || batch < 1) return fail(OCS_ERR_INVALID, "bad argument");
   OCS_TRY(upload_control(c));
-  if (c->dense && batch >= 16384) {
+  if (c->dense) {
     LAUNCH_TRY(launch_basis_dense(false, c->nBasis, c->nT, c->nC, batch, c->d_BT.d(), dJdu, dJdv, (hipStream_t)stream));
     return OCS_OK;
   }
@@ -492,14 +492,20 @@ int ocs_nlp_objective_dev(ocs_integrator g, ocs_problem p, ocs_control c, int ba
   const size_t B = (size_t)batch;
   // Dense basis with few functions on a plain RK4Integrator: u and dJdu never touch memory, the basis is
   // applied inside the RK4 kernels (ocs_fused_control_kernels.hip).  Measured on TestOCProblem + Chebyshev-16,
-  // N = 1000 (ms per evaluation, unfused / fused): batch 64 0.80 / 0.43, 4096 0.90 / 0.44, 65536 2.54 / 0.61,
-  // 262144 6.28 / 2.02.  With 3-4 states and a small batch the wave-specialised unfused passes are kept.
+  // N = 1000 (ms per evaluation, unfused / fused, round 2): batch 64 0.80 / 0.43, 4096 0.90 / 0.44, 65536 2.54 / 0.61,
+  // 262144 6.28 / 2.02.
   const bool fusable = c->dense && g->kind == 0 && fused_control_supported(p->functor, p->nS, p->nC, c->nBasis);
-  const bool fused = fusable && c->fuse_mode != 1 && (c->fuse_mode >= 2 || p->nS <= 2 || batch >= 8192);
   // ... and where the shapes allow it (one state row, whole blocks and tiles) on the wave-specialised state pass and the
   // adjoint scan with the basis products on the matrix cores (ocs_fused_wave_kernels.hip)
-  const bool fusedw = fused && c->fuse_mode != 3 && (c->fuse_mode == 2 || batch <= 32768) &&
-                      fused_wave_supported(p->functor, p->nS, p->nC, c->nBasis, g->N, batch);
+  const bool wave_ok = fusable && c->fuse_mode != 1 && c->fuse_mode != 3 && (c->fuse_mode == 2 || batch <= 32768) &&
+                       fused_wave_supported(p->functor, p->nS, p->nC, c->nBasis, g->N, batch);
+  // Otherwise the fused LANE kernels against the unfused sequence (basis kernels + the automatic pass pair), re-measured in round 4
+  // with the time-parallel dense basis kernels (Chebyshev-16, N = 1000, us per evaluation, unfused / fused lane):
+  //   nS = 2: 8192 281 / 376, 16384 507 / 387;  nS = 3: 16384 712 / 752, 32768 1066 / 881;  nS = 4: 8192 411 / 868,
+  //   16384 750 / 895, 32768 1260 / 1009, 65536 1946 / 1198   (profiles/r04_fusion_by_batch.log)
+  const bool fused = fusable && c->fuse_mode != 1 &&
+                     (c->fuse_mode >= 2 || wave_ok || batch >= (p->nS <= 2 ? 16384 : 32768));
+  const bool fusedw = fused && wave_ok;
   // Banded basis (PWLinear, PWConstant): the same with two live coefficient rows per trajectory
   // (ocs_fused_banded_kernels.hip)
   // Measured (TestOCProblem, N = 500, PWLinear 101 points; ms per evaluation unfused / fused): batch 4096 0.16 / 0.31,

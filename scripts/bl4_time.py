@@ -7,14 +7,15 @@ ocs = g.load_package()
 dev = torch.device('cuda:0')
 N, nB = int(os.environ.get('NSTEPS', '1000')), int(os.environ.get('NB', '16'))
 integ = ocs.RK4Integrator(np.linspace(0, 10, N + 1))
-prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]])
+NS = int(os.environ.get("NS", "0"))   # 0: TestOCProblem (BL-4); 1..4: LogisticK with that many states
+prob = ocs.TestOCProblem({"c": 1.5, "m": 3.0, "r": 0.05}, [[0.0, 1.0]]) if NS == 0 else ocs.LogisticProblem([3.0, 2.5, 2.0, 1.5][:NS], 1.5, 0.05, [[0.0, 1.0]])
 cc = ocs.ChebyshevControl(integ.t, nB, 1)
 for batch in [int(b) for b in os.environ.get('BATCHES', '64,8192,65536').split(',')]:
     rng = np.random.default_rng(20260403)
     V = 0.05 * rng.normal(size=(nB, batch)) / np.arange(1, nB + 1)[:, None]
     V[0] += 0.5
     Vd = torch.tensor(V, device=dev)
-    x0 = torch.ones((1, batch), dtype=torch.float64, device=dev)
+    x0 = torch.ones((max(NS, 1), batch), dtype=torch.float64, device=dev)
     res = {}
     for mode in os.environ.get('MODES', 'on,lane').split(','):
         cc.set_fusion(mode)
