@@ -303,6 +303,9 @@ int ocs_integrator_destroy(ocs_integrator g) {
   if (g->lqws) lq_workspace_free(g->lqws);
   g->d_ustar.release();
   g->d_lam2.release();
+  g->d_utail.release();
+  g->d_lamtail.release();
+  g->d_J2.release();
   if (g->stream) (void)hipStreamDestroy(g->stream);
   DevBuf* bufs[] = {&g->d_HT, &g->d_T, &g->d_TC, &g->d_TU, &g->d_REC, &g->d_RECS, &g->d_split, &g->d_x0, &g->d_u, &g->d_x, &g->d_J,
                     &g->d_lam, &g->d_dJdu, &g->d_lamT, &g->d_stage, &g->d_ck};
@@ -368,6 +371,23 @@ int ocs_compute_states_dev(ocs_integrator g, ocs_problem p, int batch, const dou
   const double* xT = g->ck + (size_t)g->N * (p->nS + 1) * batch;  // x(1:nS, end): rows are contiguous [nS][B]
   ocs_integrator_s* g2 = g->leg2;
   OCS_TRY(g2->d_ck.ensure(sizeof(double) * (size_t)(p->nS + 1) * (g2->N + 1) * batch));
+  // The tail leg has a constant control.  The lane kernels take it as a parameter and read nothing (the mapping for a full
+  // chip); where the wave-specialised kernels would be chosen (small batches: the lane kernels are chain-bound, 650 against
+  // 125 us for the tail at batch 4096) the tail runs on them, on SAMPLES of the constant control kept with the handle.
+  OCS_TRY(bind_problem(g2, p, batch, s));
+  g2->tail_wave = g2->mapping == MAP_AUTO && tail_leg_wave_ok(describe(p), describe(g2), batch);
+  if (g2->tail_wave) {
+    const size_t nU = (size_t)(2 * g2->N + 1) * p->nC * batch;
+    OCS_TRY(g2->d_utail.ensure(sizeof(double) * nU));
+    if (g2->utail_batch != batch) {
+      LAUNCH_TRY(launch_fill_rows(2 * g2->N + 1, p->nC, batch, g->d_ustar.d(), g2->d_utail.d(), s));
+      g2->utail_batch = batch;
+    }
+    OCS_TRY(g2->d_J2.ensure(sizeof(double) * (size_t)batch));
+    OCS_TRY(leg_forward(g2, p, batch, xT, g2->d_utail.d(), g2->d_ck.d(), g2->d_J2.d(), FwdOpts(), s));
+    LAUNCH_TRY(launch_add_vec(batch, J, g2->d_J2.d(), J, s));   // J = J1 + J2   :24
+    return OCS_OK;
+  }
   FwdOpts o2;
   o2.uconst = true;
   o2.Jadd = J;
@@ -399,13 +419,22 @@ int ocs_compute_adjoints_dev(ocs_integrator g, ocs_problem p, int batch, const d
       return fail(OCS_ERR_ORDER, "tail leg has no forward pass");
     OCS_TRY(bind_problem(g2, p, batch, s));
     OCS_TRY(g->d_lam2.ensure(sizeof(double) * (size_t)(p->nS + 1) * batch));
-    BwdOpts o2;
-    o2.mapping = g2->mapping;
-    o2.uconst = true;
-    o2.lam0 = g->d_lam2.d();
-    LAUNCH_TRY(launch_backward(describe(p), describe(g2), batch, g2->ck, g->d_ustar.d(), nullptr, nullptr, nullptr,
-                               o2, s));
-    lamT = g->d_lam2.d();
+    if (g2->tail_wave && g2->utail_batch == batch) {   // (the state pass of the tail ran on the sampled control: so does this)
+      OCS_TRY(g2->d_lamtail.ensure(sizeof(double) * (size_t)(g2->N + 1) * (p->nS + 1) * batch));
+      BwdOpts o2;
+      o2.mapping = g2->mapping;
+      LAUNCH_TRY(launch_backward(describe(p), describe(g2), batch, g2->ck, g2->d_utail.d(), nullptr, g2->d_lamtail.d(),
+                                 nullptr, o2, s));
+      lamT = g2->d_lamtail.d();   // lam2(:, 1): the first column
+    } else {
+      BwdOpts o2;
+      o2.mapping = g2->mapping;
+      o2.uconst = true;
+      o2.lam0 = g->d_lam2.d();
+      LAUNCH_TRY(launch_backward(describe(p), describe(g2), batch, g2->ck, g->d_ustar.d(), nullptr, nullptr, nullptr,
+                                 o2, s));
+      lamT = g->d_lam2.d();
+    }
   }
   LAUNCH_TRY(launch_backward(describe(p), describe(g), batch, g->ck, u, lamT, lam, dJdu, o, s));
   return OCS_OK;

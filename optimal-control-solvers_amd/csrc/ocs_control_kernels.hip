@@ -180,11 +180,19 @@ __global__ void k_scatter_rows(int nrows, int batch, const int* __restrict__ idx
 }
 
 // out[j][c][b] = val[c]  (u0 = ControlBounds(:,1)*ones(1,length(t)), fb_sweep.m:23)
+__global__ void k_add_vec(int n, const double* __restrict__ a, const double* __restrict__ b, double* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = a[i] + b[i];
+}
 __global__ void k_fill_rows(int ncols, int nC, int batch, const double* __restrict__ val, double* __restrict__ out) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
   if (b >= batch || j >= ncols) return;
   for (int c = 0; c < nC; ++c) out[((size_t)j * nC + c) * batch + b] = val[c];
+}
+int launch_add_vec(int n, const double* a, const double* b, double* out, hipStream_t s) {
+  k_add_vec<<<dim3((n + 255) / 256), dim3(256), 0, s>>>(n, a, b, out);
+  return hip_rc2(hipGetLastError());
 }
 int launch_fill_rows(int ncols, int nC, int batch, const double* val, double* out, hipStream_t s) {
   k_fill_rows<<<dim3((batch + 255) / 256, ncols), dim3(256), 0, s>>>(ncols, nC, batch, val, out);

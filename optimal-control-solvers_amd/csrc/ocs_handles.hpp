@@ -159,6 +159,11 @@ struct ocs_integrator_s {
   ocs_integrator_s* leg2 = nullptr;   // integrator2 of RK4InfiniteIntegrator.m:13-14
   std::vector<double> ustar;          // uStar (nC)
   DevBuf d_ustar, d_lam2;             // device uStar [nC]; lam2(:,1) [nAug][B]
+  // tail leg of RK4InfiniteIntegrator on the wave-specialised kernels (small batches): the constant control as samples
+  // [2N+1][nC][B], the tail's lam [N+1][nAug][B] (its first column is the main leg's lamT), the tail's objective [B]
+  DevBuf d_utail, d_lamtail, d_J2;
+  int utail_batch = 0;
+  bool tail_wave = false;
   int N = 0;
   std::vector<double> tspan, t, h;
   DevBuf d_HT, d_T, d_TC, d_TU, d_REC, d_RECS, d_split;

@@ -186,6 +186,11 @@ bool basis_dense_supported(int nBasis);
 int launch_basis_dense(bool expand, int nBasis, int nT, int nC, int batch, const double* BT, const double* in,
                        double* out, hipStream_t s);
 int launch_fill_rows(int ncols, int nC, int batch, const double* val, double* out, hipStream_t s);
+// out[i] = a[i] + b[i]
+int launch_add_vec(int n, const double* a, const double* b, double* out, hipStream_t s);
+// RK4InfiniteIntegrator's tail leg (constant control): true where the wave-specialised state pass would be chosen for this grid
+// and batch -- the tail then runs on samples of the constant control instead of the lane kernels (ocs_api.cpp)
+bool tail_leg_wave_ok(const ProblemDesc& p, const GridDesc& g, int batch);
 int launch_gather_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
 int launch_scatter_rows(int nrows, int batch, const int* idx, const double* src, double* dst, hipStream_t s);
 

@@ -217,6 +217,10 @@ bool forward_gate_supported(const ProblemDesc& p, const GridDesc& g, int batch) 
   const int tpw = forward_is_vector(p) ? 64 : 64 / p.nS;
   return pipeline_steps(p, g.N, batch, false) == g.N && g.N > 0 && batch / tpw <= fold_wg_limit();
 }
+bool tail_leg_wave_ok(const ProblemDesc& p, const GridDesc& g, int batch) {
+  if (p.functor == Functor::LQ) return false;
+  return choose_mapping(p, g.N, batch, MAP_AUTO, true, false, true) == MAP_PIPELINE;
+}
 // any state pass the sweep launches with `frozen` set (pipeline kernels, split passes, the lane kernel): FwdOpts::gate
 bool forward_gate_any(const ProblemDesc& p) { return p.functor != Functor::LQ; }
 

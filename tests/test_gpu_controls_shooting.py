@@ -126,6 +126,29 @@ def test_infinite_integrator(ocs, oracle):
         assert abs(J[b] - Jo) < RTOL * abs(Jo) and relerr(dJdv[:, b], do) < RTOL
 
 
+@pytest.mark.parametrize("nS,N,N2,batch", [(1, 200, 152, 128), (2, 64, 64, 96), (4, 48, 40, 32), (2, 64, 60, 96), (2, 64, 64, 70)])
+def test_infinite_integrator_tail_leg_mappings(ocs, oracle, nS, N, N2, batch):
+    """RK4InfiniteIntegrator.m:12-30 on batches where the tail leg (constant control uStar) runs on the wave-specialised kernels
+    with the control as samples (whole blocks of 8 steps, whole tiles of 64/nS trajectories) and where it stays on the lane kernels
+    (N2 = 60 is split, batch 70 is ragged): x, J = J1 + J2, lam (with lamT = lam2(:,1)) and dJdu against the oracle."""
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    us = 0.4
+    tspan, tx = oracle.linspace(0, 2.0, N + 1), oracle.linspace(2.0, 4.0, N2 + 1)
+    pg, po = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS), oracle.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    gi, go = ocs.RK4InfiniteIntegrator(tspan, tx, [us]), oracle.RK4InfiniteIntegrator(tspan, tx, [us])
+    rng = np.random.default_rng(N + N2 + batch)
+    u = rng.uniform(0.05, 0.45, (1, 2 * N + 1, batch))
+    x0 = rng.uniform(0.8, 2.0, (nS, batch))
+    for rep in range(2):        # (the second call re-uses the sampled control kept with the handle)
+        x, J = gi.compute_states(pg, x0, u)
+        lam, dJdu = gi.compute_adjoints(pg, u)
+        for b in sorted({0, batch // 2, batch - 1}):
+            xo, Jo = go.compute_states(po, x0[:, b], u[:, :, b])
+            lamo, do = go.compute_adjoints(po, u[:, :, b])
+            assert relerr(x[:, :, b], xo) < RTOL and abs(J[b] - Jo) < RTOL * abs(Jo)
+            assert relerr(lam[:, :, b], lamo) < RTOL and relerr(dJdu[:, :, b], do) < RTOL
+
+
 def test_device_objective_bl4_shape(ocs, oracle):
     """BASELINE config 4 shape (Chebyshev-16 objective+gradient) on device buffers, reduced batch."""
     import torch
