@@ -205,25 +205,37 @@ int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* 
     kq[j] = lo;
     sq[j] = lo >= 0 && lo < n - 1 ? q - x[lo] : 0.0;
   }
-  DevBuf TN, HN, W1, W2, IH, KQ, SQ;  // released on return (the launch is synchronised below)
-  struct Rel {
-    DevBuf* b[7];
-    ~Rel() {
-      for (DevBuf* p : b) p->release();
-    }
-  } rel{{&TN, &HN, &W1, &W2, &IH, &KQ, &SQ}};
-  OCS_TRY(upload(TN, x, sizeof(double) * n));
-  OCS_TRY(upload(HN, h.data(), sizeof(double) * (n - 1)));
-  OCS_TRY(upload(W1, w1.data(), sizeof(double) * n));
-  OCS_TRY(upload(W2, w2.data(), sizeof(double) * n));
-  OCS_TRY(upload(IH, ih.data(), sizeof(double) * (n - 1)));
-  OCS_TRY(upload(KQ, kq.data(), sizeof(int) * nq));
-  OCS_TRY(upload(SQ, sq.data(), sizeof(double) * nq));
-  const FbsTables tb{n, TN.d(), HN.d(), W1.d(), W2.d(), nullptr, IH.d(), nullptr};
+  // The seven small tables in ONE device buffer that the calling thread keeps between calls (grow-only, per device): seven
+  // hipMalloc / hipFree pairs per call were most of the call's 250-450 us at batch 4096.  One staged host array, one copy.
+  const size_t nd = (size_t)n * 5 + (size_t)nq * 2 + 8;   // doubles: TN n | HN n | W1 n | W2 n | IH n | SQ nq | KQ (ints) nq
+  std::vector<double> stage(nd, 0.0);
+  double* hp = stage.data();
+  memcpy(hp, x, sizeof(double) * n);
+  memcpy(hp + n, h.data(), sizeof(double) * (n - 1));
+  memcpy(hp + 2 * (size_t)n, w1.data(), sizeof(double) * n);
+  memcpy(hp + 3 * (size_t)n, w2.data(), sizeof(double) * n);
+  memcpy(hp + 4 * (size_t)n, ih.data(), sizeof(double) * (n - 1));
+  memcpy(hp + 5 * (size_t)n, sq.data(), sizeof(double) * nq);
+  memcpy(hp + 5 * (size_t)n + nq, kq.data(), sizeof(int) * nq);
+  struct Scratch {
+    DevBuf buf;
+    int device = -1;
+  };
+  static thread_local Scratch scratch;
+  int devnow = 0;
+  HIP_TRY(hipGetDevice(&devnow));
+  if (scratch.device != devnow) {   // (a buffer of another device: dropped, not freed from here)
+    scratch.buf = DevBuf();
+    scratch.device = devnow;
+  }
+  OCS_TRY(scratch.buf.ensure(sizeof(double) * nd));
+  HIP_TRY(hipMemcpyAsync(scratch.buf.p, hp, sizeof(double) * nd, hipMemcpyHostToDevice, s));
+  double* dp = scratch.buf.d();
+  const FbsTables tb{n, dp, dp + n, dp + 2 * (size_t)n, dp + 3 * (size_t)n, nullptr, dp + 4 * (size_t)n, nullptr};
   // ('nearest' and 'next' pick a sample like 'previous' does: the kernel's sample-index mode)
   const int kmethod = (method == OCS_INTERP_NEAREST || method == OCS_INTERP_NEXT) ? OCS_INTERP_PREVIOUS : method;
-  LAUNCH_TRY(launch_interp(kmethod, tb, nComp, nq, (const int*)KQ.p, SQ.d(), batch, v, out, s));
-  HIP_TRY(hipStreamSynchronize(s));
+  LAUNCH_TRY(launch_interp(kmethod, tb, nComp, nq, (const int*)(dp + 5 * (size_t)n + nq), dp + 5 * (size_t)n, batch, v, out, s));
+  HIP_TRY(hipStreamSynchronize(s));   // (the staged host array lives until here)
   return OCS_OK;
 }
 
