@@ -6,7 +6,7 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), '..'
 import __graft_entry__ as g
 ocs = g.load_package()
 dev = torch.device('cuda:0')
-nS, N, batch = int(os.environ.get('NS', '4')), 1000, int(os.environ.get('BATCH', '4096'))
+nS, N, batch = int(os.environ.get('NS', '4')), int(os.environ.get('NSTEPS', '1000')), int(os.environ.get('BATCH', '4096'))
 m = [3.0, 2.5, 2.0, 1.5][:nS]
 prob = ocs.LogisticProblem(m, 1.5, 0.05, [[0.0, 1.0]])
 # UNIFORM=1: steps of 2^-7 (bitwise uniform: the kernels keep the step sizes in registers); default MATLAB-style linspace
