@@ -162,7 +162,12 @@ __global__ __launch_bounds__((P2Cfg<P::NS, NKS, TPW_>::NWAVE * 64)) void k_forwa
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int nb = a.N / D;
-  const int bw = blockIdx.x * TPW;
+  // A batch that is not a multiple of the tile: the LAST workgroup takes the last TPW trajectories, overlapping its neighbour --
+  // the overlap is computed twice with the same operations and stored twice with the same values (nothing of this kernel is
+  // accumulated across trajectories).  The launcher asks for it only with batch >= TPW and an even row distance (the 16-byte
+  // DMA chunks stay aligned).
+  const int bw_ = blockIdx.x * TPW;
+  const int bw = bw_ + TPW <= a.batch ? bw_ : a.batch - TPW;
   if (a.gate && *a.gate == 0) return;
   const uniform_ptr PS = as_uniform(a.ps);
   const size_t colB = (size_t)NAUG * B;

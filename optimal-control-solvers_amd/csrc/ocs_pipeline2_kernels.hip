@@ -54,7 +54,7 @@ int launch_forward_pv(const ProblemDesc& p, const GridDesc& g, int batch, const 
 template <class P, bool UNI>
 static void run_forward_p2u(const FwdArgsP2& a, hipStream_t s) {
   using C_ = P2Cfg<P::NS>;
-  const dim3 grid(a.batch / C_::TPW), block(C_::NWAVE * 64);
+  const dim3 grid((a.batch + C_::TPW - 1) / C_::TPW), block(C_::NWAVE * 64);   // (a ragged last tile overlaps its neighbour)
   // One workgroup per CU: the recursion wave must have its SIMD to itself.  With less than half of the CU's LDS per
   // workgroup the dispatcher packs two workgroups on one CU while other CUs stay empty (measured: 102 us against
   // 60 us); unused dynamic LDS keeps a second workgroup out.
@@ -82,13 +82,14 @@ int launch_forward_p2(const ProblemDesc& p, const GridDesc& g, int batch, const 
                       double* x, double* J, const int* frozen, int ld, hipStream_t s, bool no_cost_row,
                       const int* gate) {
   if (!pipeline_problem_ok(p) || !pipeline_shape_ok(p.nS, g.N, batch, false)) return -1;
+  if (batch % (64 / p.nS) != 0 && (ld ? ld : batch) % 2 != 0) return -1;   // (ragged last tile: even row distance only)
   if (p.functor == Functor::User) {   // the hipRTC instances of the same kernel template (generic row functions)
     const FwdArgsP2 au{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, frozen, ld, no_cost_row ? 1 : 0, gate};
     static_assert(p2_waves(1) == P2Cfg<1>::NWAVE && p2_waves(2) == P2Cfg<2>::NWAVE && p2_waves(4) == P2Cfg<4>::NWAVE,
                   "launch shape of the hipRTC instances");
     const int TPW = 64 / p.nS, nwave = p2_waves(p.nS);
     void* args[] = {(void*)&au};
-    return jit_launch(p.user, x ? UK_FWD_P2_X : UK_FWD_P2_J, dim3(batch / TPW), dim3(nwave * 64), args, s,
+    return jit_launch(p.user, x ? UK_FWD_P2_X : UK_FWD_P2_J, dim3((batch + TPW - 1) / TPW), dim3(nwave * 64), args, s,
                       p.nS == 1 ? 0u : 48u * 1024u);
   }
   const FwdArgsP2 a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, frozen, ld, no_cost_row ? 1 : 0, gate};

@@ -1397,8 +1397,10 @@ bool pipeline_supported(Functor f, int nS, int nC) {
 }
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward) {
   const int D = 8, TPW = 64 / nS;
-  (void)backward;
-  return N >= D && N % D == 0 && batch % TPW == 0;
+  if (N < D || N % D != 0) return false;
+  // whole tiles; the state pass (k_forward_p2) also takes a ragged last tile as a workgroup that overlaps its neighbour, given
+  // at least one tile and an even row distance (ocs_pipeline2_kernel.hpp)
+  return batch % TPW == 0 || (!backward && batch > TPW && batch % 2 == 0);
 }
 int pipeline_block_steps() { return 8; }
 
@@ -1423,6 +1425,7 @@ int launch_forward_pl(const ProblemDesc& p, const GridDesc& g, int batch, const 
   if (!pipeline_shape_ok(p.nS, g.N, batch, false) || (frozen && !dump)) return -1;
   static const bool v1 = getenv("OCS_FWD_V1") != nullptr;   // the previous kernel, for A/B timing
   if (!v1) return launch_forward_p2(p, g, batch, x0, u, x, J, frozen, ld, s, no_cost_row, gate);
+  if (batch % (64 / p.nS) != 0) return -1;   // (the previous kernel: whole tiles only)
   FwdArgsPL a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, nullptr, frozen, dump, ld, no_cost_row ? 1 : 0, gate};
 #ifdef OCS_PL_STAMPS
   static long long* dbg = nullptr;
