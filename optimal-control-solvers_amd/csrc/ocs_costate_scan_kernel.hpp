@@ -70,7 +70,7 @@ __global__ __launch_bounds__(W * 64) void k_costate_scan(const CostateScanArgs a
   const size_t B = (size_t)a.batch;
   const int N = a.N;
   if (a.gate && *a.gate == 0) return;
-  const int b = blockIdx.x * TPW + tl;   // (whole tiles)
+  const int b = tile_base(blockIdx.x, TPW, a.batch) + tl;   // (a ragged last tile overlaps its neighbour)
   const uniform_ptr PS = as_uniform(a.ps);
   const typename P::RowPar rp = P::load_row(ParamSrc{PS, a.pb, a.pmask, B, b}, r);
   const bool fz = a.frozen != nullptr && a.frozen[b] != 0;

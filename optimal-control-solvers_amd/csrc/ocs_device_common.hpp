@@ -17,6 +17,15 @@ __device__ static inline void chain_wave_priority() {
 
 #define OCS_INLINE __attribute__((always_inline))
 
+// First trajectory of a workgroup's tile of TPW trajectories.  A batch that is not a multiple of the tile: the LAST workgroup takes
+// the last TPW trajectories, overlapping its neighbour -- the overlap is computed twice with the same operations and stored twice
+// with the same values (the tiled kernels accumulate nothing across trajectories; counters of active instances may count an
+// instance twice, they are only compared with zero).  Launchers ask for it with batch > TPW and an even batch (16-byte DMA chunks).
+__device__ static inline int tile_base(int block, int TPW, int batch) {
+  const int b0 = block * TPW;
+  return b0 + TPW <= batch ? b0 : batch - TPW;
+}
+
 // Wave-uniform read-only tables (step sizes, time coefficients, shared parameters) are read
 // through the constant address space so the backend emits scalar (s_load) instead of
 // per-lane vector loads: `__restrict__` on struct members does not reach alias analysis.

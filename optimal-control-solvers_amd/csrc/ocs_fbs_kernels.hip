@@ -53,7 +53,7 @@ bool costate_forms_midpoints(const ProblemDesc& p, int N, int batch) {
     }
     // problems given as row functions: the scan that reads the control samples
     return user_rowsep(p.user) && p.nC == 1 && (p.nS == 1 || p.nS == 2 || p.nS == 4) && N >= 8 && N % 8 == 0 &&
-           batch % (64 / p.nS) == 0;
+           tile_ok(batch, 64 / p.nS);
   }
   return costate_pl_ok(p.functor, p.nS, p.nC, N, batch) && batch / (64 / p.nS) <= fold_wg_limit();
 }

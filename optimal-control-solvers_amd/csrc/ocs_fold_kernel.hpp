@@ -113,7 +113,7 @@ __global__ __launch_bounds__(FoldCfg<P::NS>::NWAVE * 64) void k_forward_cc(const
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)a.batch;
   const int N = a.N, nb = N / D;
-  const int bw = blockIdx.x * TPW;
+  const int bw = tile_base(blockIdx.x, TPW, a.batch);
   if (a.gate && *a.gate == 0) return;
   const uniform_ptr PS = as_uniform(a.ps);
   const size_t colB = (size_t)NAUG * B;

@@ -13,15 +13,15 @@ static inline int hip_rc7(hipError_t e) { return e == hipSuccess ? 0 : (int)e; }
 bool fold_supported(const ProblemDesc& p, const GridDesc& g, int batch) {
   if (p.nC != 1 || !(p.nS == 1 || p.nS == 2 || p.nS == 4)) return false;
   if (p.functor == Functor::User)   // hipRTC instances; the costate pass is the scan kernel (costate_scan_ok)
-    return user_fold(p.user) && g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 && costate_scan_ok(p, g, batch) && g.TU && g.REC;
+    return user_fold(p.user) && g.N >= 8 && g.N % 8 == 0 && tile_ok(batch, 64 / p.nS) && costate_scan_ok(p, g, batch) && g.TU && g.REC;
   if (p.functor != Functor::Logistic) return false;
-  return g.N >= 8 && g.N % 8 == 0 && batch % (64 / p.nS) == 0 && costate_forms_midpoints(p, g.N, batch) && g.TU && g.REC;
+  return g.N >= 8 && g.N % 8 == 0 && tile_ok(batch, 64 / p.nS) && costate_forms_midpoints(p, g.N, batch) && g.TU && g.REC;
 }
 
 template <class P>
 static void run_forward_cc(const FwdArgsCC& a, bool uniform, hipStream_t s) {
   using C_ = FoldCfg<P::NS>;
-  const dim3 grid(a.batch / C_::TPW), block(C_::NWAVE * 64);
+  const dim3 grid(tile_count(a.batch, C_::TPW)), block(C_::NWAVE * 64);
   if (uniform)
     k_forward_cc<P, true><<<grid, block, 0, s>>>(a);
   else
@@ -36,7 +36,7 @@ int launch_forward_cc(const ProblemDesc& p, const GridDesc& g, int batch, const 
   if (p.functor == Functor::User) {
     const int nwave = p.nS == 1 ? FoldCfg<1>::NWAVE : (p.nS == 2 ? FoldCfg<2>::NWAVE : FoldCfg<4>::NWAVE);
     void* args[] = {(void*)&a};
-    return jit_launch(p.user, g.uniform ? UK_FWD_CC_UNI : UK_FWD_CC, dim3(batch / (64 / p.nS)), dim3(nwave * 64), args, s);
+    return jit_launch(p.user, g.uniform ? UK_FWD_CC_UNI : UK_FWD_CC, dim3(tile_count(batch, 64 / p.nS)), dim3(nwave * 64), args, s);
   }
   if (p.nS == 1)
     run_forward_cc<LogisticK<1>>(a, g.uniform, s);

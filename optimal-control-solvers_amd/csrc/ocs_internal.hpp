@@ -74,6 +74,10 @@ size_t scan_recs_doubles(int N);
 size_t scan_recs_front();
 int launch_build_recs(int N, int rs, int sco, const double* REC, double* RECS_base, hipStream_t s);
 bool pipeline_supported(Functor f, int nS, int nC);
+// tiles of `tile` trajectories: whole, or with a ragged last tile taken by a workgroup that overlaps its neighbour (tile_base,
+// ocs_device_common.hpp): more than one tile and an even batch
+inline bool tile_ok(int batch, int tile) { return batch % tile == 0 || (batch > tile && batch % 2 == 0); }
+inline int tile_count(int batch, int tile) { return (batch + tile - 1) / tile; }
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward);  // nSTEPS multiple of the block, batch of the tile
 int pipeline_block_steps();  // the pipeline kernels take whole blocks of this many steps
 // wave-specialised costate pass of the sweep (registry problems whose adjoint right-hand side does not read u)

@@ -897,7 +897,7 @@ __global__ __launch_bounds__(128) void k_costate_pl(const CostateArgsPL a) {
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int N = a.N, nb = N / D;
-  const int bw = blockIdx.x * TPW;
+  const int bw = tile_base(blockIdx.x, TPW, a.batch);
   if (wave == 0) {
     // ---------------- M: HBM -> LDS ----------------
     auto issue = [&](int j) OCS_INLINE {
@@ -1108,7 +1108,7 @@ __global__ __launch_bounds__(MET ? 576 : 320) void k_costate_plx(const CostateXA
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)(a.ld ? a.ld : a.batch);
   const int N = a.N, nb = N / D;
-  const int bw = blockIdx.x * TPW;
+  const int bw = tile_base(blockIdx.x, TPW, a.batch);
   if (aa.gate && *aa.gate == 0) return;
   if (wave == 0) {
     // ---------------- M: HBM -> LDS ----------------
@@ -1311,7 +1311,7 @@ __global__ __launch_bounds__(MET ? 576 : 320) void k_costate_plx(const CostateXA
 
 template <class P>
 static void run_costate_plx(const CostateXArgs& a, hipStream_t s) {
-  const dim3 grid(a.c.batch / (64 / P::NS)), block(320);
+  const dim3 grid(tile_count(a.c.batch, 64 / P::NS)), block(320);
   if (a.c.frozen)
     k_costate_plx<P, true><<<grid, block, 0, s>>>(a);
   else
@@ -1350,7 +1350,7 @@ int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const
     return launch_costate_scan_met(p, g, batch, x, ldx, PR, lb, ub, relTol, absTol, sweep, status, maxChange, nactive, lam, s, gate);
   const CostateXArgs a{CostateArgsPL{g.N, batch, 0, g.REC, p.ps, p.pb, p.pmask, x, ldx, nullptr, status, nullptr, lam},
                        PR, gate, g.TU, lb, ub, relTol, absTol, sweep, status, maxChange, nactive};
-  const dim3 grid(batch / (64 / p.nS)), block(576);
+  const dim3 grid(tile_count(batch, 64 / p.nS)), block(576);
   if (p.nS == 1)
     k_costate_plx<LogisticK<1>, true, true><<<grid, block, 0, s>>>(a);
   else if (p.nS == 2)
@@ -1366,11 +1366,11 @@ int launch_costate_met(const ProblemDesc& p, const GridDesc& g, int batch, const
 //  dFdx_times_vec does not read u -- LogisticK -- which pipeline_supported() guarantees; a functor whose adjoint
 //  right-hand side reads u must take launch_costate's lane kernel)
 bool costate_pl_ok(Functor f, int nS, int nC, int N, int batch) {
-  return pipeline_supported(f, nS, nC) && N >= 8 && N % 8 == 0 && batch % (64 / nS) == 0;
+  return pipeline_supported(f, nS, nC) && N >= 8 && N % 8 == 0 && tile_ok(batch, 64 / nS);
 }
 template <class P>
 static void run_costate_pl(const CostateArgsPL& a, hipStream_t s) {
-  const dim3 grid(a.batch / (64 / P::NS)), block(128);
+  const dim3 grid(tile_count(a.batch, 64 / P::NS)), block(128);
   if (a.frozen)
     k_costate_pl<P, true><<<grid, block, 0, s>>>(a);
   else

@@ -123,21 +123,21 @@ bool costate_scan_ok(const ProblemDesc& p, const GridDesc& g, int batch) {
   // (measured, TestOCProblem, N = 1000, ms per solve of 12 sweeps, scan / serial: batch 2048 2.00 / 2.07, 4096 2.00 / 2.07,
   // 16 384 2.24 / 2.20 -- at BL-3's batch either pass moves its 24 B per instance-step at ~4.9 TB/s).
   const bool shape = g.RECS && g.N >= 8 && g.N % 8 == 0 && (p.nS == 1 || p.nS == 2 || p.nS == 4) && p.nC == 1 &&
-                     batch % (64 / p.nS) == 0;
+                     tile_ok(batch, 64 / p.nS);
   // user problems that declare the costate equation free of u: the scan is their costate kernel at every batch
   if (p.functor == Functor::User) return user_fold(p.user) && shape;
   return !off && scan_supported(p.functor, p.nS, p.nC) && shape && (on || batch / (64 / p.nS) <= 128);
 }
 template <class P, bool MET>
 static void run_costate_scan(const CostateScanArgs& a, hipStream_t s) {
-  k_costate_scan<P, kScanW, kScanL, MET><<<dim3(a.batch / (64 / P::NS)), dim3(kScanW * 64), 0, s>>>(a);
+  k_costate_scan<P, kScanW, kScanL, MET><<<dim3(tile_count(a.batch, 64 / P::NS)), dim3(kScanW * 64), 0, s>>>(a);
 }
 template <bool MET>
 static int launch_costate_scan_t(const ProblemDesc& p, const CostateScanArgs& a, hipStream_t s) {
   if (p.functor == Functor::User) {
     if (!MET) return -1;   // (only the sweep's costate pass is instantiated for user problems)
     void* args[] = {(void*)&a};
-    return jit_launch(p.user, UK_COSTATE_SCAN_MET, dim3(a.batch / (64 / p.nS)), dim3(kScanW * 64), args, s);
+    return jit_launch(p.user, UK_COSTATE_SCAN_MET, dim3(tile_count(a.batch, 64 / p.nS)), dim3(kScanW * 64), args, s);
   }
   if (p.nS == 1)
     run_costate_scan<LogisticK<1>, MET>(a, s);
@@ -158,7 +158,7 @@ int launch_costate_scan(const ProblemDesc& p, const GridDesc& g, int batch, cons
 // any user problem given as row functions: the scan that reads the control samples (hipRTC instance)
 bool costate_scan_u_ok(const ProblemDesc& p, const GridDesc& g, int batch) {
   return p.functor == Functor::User && user_rowsep(p.user) && g.RECS && g.N >= 8 && g.N % 8 == 0 &&
-         (p.nS == 1 || p.nS == 2 || p.nS == 4) && p.nC == 1 && batch % (64 / p.nS) == 0;
+         (p.nS == 1 || p.nS == 2 || p.nS == 4) && p.nC == 1 && tile_ok(batch, 64 / p.nS);
 }
 int launch_costate_scan_u(const ProblemDesc& p, const GridDesc& g, int batch, const double* x, int ldx, const double* PR,
                           const double* u, const int* frozen, double* lam, hipStream_t s, const int* gate) {
@@ -167,7 +167,7 @@ int launch_costate_scan_u(const ProblemDesc& p, const GridDesc& g, int batch, co
   a.N = g.N; a.batch = batch; a.RECS = g.RECS; a.PR = PR; a.ps = p.ps; a.pb = p.pb; a.pmask = p.pmask;
   a.x = x; a.ldx = ldx; a.frozen = frozen; a.lam = lam; a.gate = gate; a.u = u;
   void* args[] = {(void*)&a};
-  return jit_launch(p.user, UK_COSTATE_SCAN_U, dim3(batch / (64 / p.nS)), dim3(kScanW * 64), args, s);
+  return jit_launch(p.user, UK_COSTATE_SCAN_U, dim3(tile_count(batch, 64 / p.nS)), dim3(kScanW * 64), args, s);
 }
 // any user problem given as full-vector methods, nS <= 4, nC <= 2 (hipRTC instance of k_costate_vscan)
 bool costate_vscan_ok(const ProblemDesc& p, const GridDesc& g, int batch) {

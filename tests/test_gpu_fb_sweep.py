@@ -397,6 +397,33 @@ def test_fold_stress_per_instance(ocs, oracle):
         assert r["err_fold"] < 1e-11 and r["err_oracle"] < 1e-10
 
 
+@pytest.mark.parametrize("nS,batch", [(1, 70), (1, 1000), (2, 98), (4, 54), (4, 1000)])
+def test_two_kernel_sweep_on_ragged_batches(ocs, oracle, nS, batch):
+    """A batch that is not a multiple of the tile of 64/nS instances: the last workgroup of every sweep kernel takes the LAST tile,
+    overlapping its neighbour (even batches beyond one tile) -- the folded sweep (path 4) instead of the kernel-by-kernel
+    sequence; same sweep counts and solution as that sequence for every instance, the oracle at both ends of the batch."""
+    rng = np.random.default_rng(batch + nS)
+    N = 64
+    m = [3.0, 2.5, 2.0, 1.5][:nS]
+    tspan = oracle.linspace(0, 1.0, N + 1)
+    x0 = rng.uniform(0.8, 2.0, (nS, batch))
+    cs = rng.uniform(1.0, 2.0, batch)
+    prob = ocs.LogisticProblem(m, P["c"], P["r"], BOUNDS)
+    prob.set_batch_params([0], cs[None, :])
+    base = {"nERROR_PTS": N + 1, "nINTERP_PTS": 17, "nSWEEPS": 40}
+    ga, gb = ocs.RK4Integrator(tspan), ocs.RK4Integrator(tspan)
+    ra = ocs.fb_sweep_batch(prob, x0, tspan, dict(base), integrator=ga)
+    rb = ocs.fb_sweep_batch(prob, x0, tspan, dict(base, fused_update_off=1), integrator=gb)
+    assert ocs.fb_sweep_path(ga) == 4 and ocs.fb_sweep_path(gb) == 1 and batch % (64 // nS) != 0
+    assert np.array_equal(ra["sweeps"], rb["sweeps"]) and ra["sweeps"].min() > 0
+    for key in ("x", "lam", "u", "J"):
+        assert relerr(ra[key], rb[key]) < 1e-12, key
+    for b in (0, batch - 2, batch - 1):
+        ref = oracle.fb_sweep(oracle.LogisticProblem(m, cs[b], P["r"], BOUNDS), x0[:, b], tspan, base)
+        assert ra["sweeps"][b] == ref["_sweeps"] and abs(ra["J"][b] - ref["J"]) < RTOL * abs(ref["J"])
+        assert relerr(ra["x"][:, :, b], ref["x"]) < RTOL and relerr(ra["u"][:, :, b], ref["u"]) < RTOL
+
+
 def test_device_pchip_against_scipy(ocs):
     """vectorInterpolant.m:6 ('pchip') on the device against scipy's PchipInterpolator (Fritsch-Carlson with MATLAB's end
     slopes): no oracle involved.  Non-uniform nodes, monotone and oscillating data, query points on nodes and between."""

@@ -6,6 +6,11 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
+
+
+def relerr(a, b):
+    a, b = np.asarray(a, dtype=np.float64), np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
 P = {"c": 1.5, "m": 3.0, "r": 0.05}
 BOUNDS = [[0.0, 1.0]]
 
@@ -34,7 +39,7 @@ def test_multi_device_equals_single_device(ocs, oracle):
     xr, Jr = g1.compute_states(p1, x0, u)
     lamr, dr = g1.compute_adjoints(p1, u)
     assert rc == 0 and np.array_equal(x, xr) and np.array_equal(J, Jr) and np.array_equal(lam, lamr) and np.array_equal(dJdu, dr)
-    assert st["count"] == B and st["argmin"] == int(np.argmin(Jr)) and st["min_J"] == Jr.min()
+    assert st["count"] == B and st["argmin"] == int(np.argmin(Jr)) and abs(st["min_J"] - Jr.min()) < 1e-13 * abs(Jr.min())
     assert abs(st["sum_J"] - Jr.sum()) < 1e-12 * abs(Jr.sum())
     # a non-finite objective is not counted and never the minimum
     u2 = u.copy()
@@ -184,8 +189,10 @@ def test_multi_device_several_slots_on_one_gpu(ocs, oracle, monkeypatch, nslots)
         lam, dJdu = md.compute_adjoints(integs, probs, u)
     xr, Jr = g1.compute_states(p1, x0, u)
     lamr, dr = g1.compute_adjoints(p1, u)
-    assert rc == 0 and np.array_equal(x, xr) and np.array_equal(J, Jr) and np.array_equal(lam, lamr) and np.array_equal(dJdu, dr)
-    assert st["count"] == B and st["argmin"] == int(np.argmin(Jr)) and st["min_J"] == Jr.min()
+    # (a block and the whole batch may take different kernel mappings -- an even block of 102 trajectories runs the tiled state
+    #  pass with an overlapping last tile, the odd batch of 203 does not --: equal to round-off, not bit for bit)
+    assert rc == 0 and relerr(x, xr) < 1e-13 and relerr(J, Jr) < 1e-13 and relerr(lam, lamr) < 1e-13 and relerr(dJdu, dr) < 1e-13
+    assert st["count"] == B and st["argmin"] == int(np.argmin(Jr)) and abs(st["min_J"] - Jr.min()) < 1e-13 * abs(Jr.min())
     assert abs(st["sum_J"] - Jr.sum()) < 1e-12 * abs(Jr.sum())
     # device-resident blocks of unequal size
     bounds = [md.shard(B, k) for k in range(nslots)]
@@ -202,9 +209,9 @@ def test_multi_device_several_slots_on_one_gpu(ocs, oracle, monkeypatch, nslots)
     md.compute_adjoints_dev(integs, probs, ud, ld, dd)
     st2 = md.stats()
     md.synchronize()
-    assert np.array_equal(np.concatenate([t.cpu().numpy() for t in Jd]), Jr)
-    assert np.array_equal(np.concatenate([t.cpu().numpy() for t in dd], axis=2), dr.transpose(1, 0, 2))
-    assert np.array_equal(np.concatenate([t.cpu().numpy() for t in ld], axis=2), lamr.transpose(1, 0, 2))
+    assert relerr(np.concatenate([t.cpu().numpy() for t in Jd]), Jr) < 1e-13
+    assert relerr(np.concatenate([t.cpu().numpy() for t in dd], axis=2), dr.transpose(1, 0, 2)) < 1e-13
+    assert relerr(np.concatenate([t.cpu().numpy() for t in ld], axis=2), lamr.transpose(1, 0, 2)) < 1e-13
     assert st2["argmin"] == int(np.argmin(Jr)) and st2["count"] == B
     # an error on one slot comes back with its device named, and the workers survive it
     with pytest.raises(ocs.OcsError):
@@ -254,7 +261,8 @@ def test_device_buffer_helpers_and_resident_loop_on_two_slots(ocs, oracle, monke
         st = md.stats()
         ocs.nlp_objective_dev(g1, p1, c1, x0s, Vs, (), Js, Gs)
         torch.cuda.synchronize()
-        assert torch.equal(torch.cat(Jb), Js) and torch.equal(torch.cat(gb, dim=1), Gs)
+        # (blocks of 75 candidates and the batch of 150 may take different mappings: round-off level)
+        assert relerr(torch.cat(Jb).cpu().numpy(), Js.cpu().numpy()) < 1e-13 and relerr(torch.cat(gb, dim=1).cpu().numpy(), Gs.cpu().numpy()) < 1e-12
         assert st["argmin"] == int(torch.argmin(Js)) and st["count"] == B
         for v, g in zip(vb, gb):
             v -= 1e-2 * g
