@@ -173,7 +173,7 @@ static int pipeline_steps(const ProblemDesc& p, int N, int batch, bool backward)
   // (user problems given as row functions have the state-pass kernel only: their adjoint pass is the scan)
   if (backward ? !pipeline_supported(p.functor, p.nS, p.nC) : !pipeline_problem_ok(p)) {
     // any other problem with nS <= 4, nC <= 2: the vector-lane state pass (whole tiles of 64 trajectories)
-    if (!backward && vector_problem_ok(p) && N1 >= D && batch >= 64 && batch % 64 == 0) return N1;
+    if (!backward && vector_problem_ok(p) && N1 >= D && batch >= 64 && tile_ok(batch, 64)) return N1;
     return 0;
   }
   if (N1 < D || !pipeline_shape_ok(p.nS, N1, batch, backward)) return 0;

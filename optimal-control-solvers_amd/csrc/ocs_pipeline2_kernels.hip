@@ -28,7 +28,7 @@ bool vector_problem_ok(const ProblemDesc& p) {
 template <class P>
 static void run_forward_pv(const FwdArgsP2& a, hipStream_t s) {
   static_assert(PVCfg<P::NS, P::NC>::NWAVE == kPvWaves, "launch shape of the hipRTC instances");
-  const dim3 grid(a.batch / 64), block(kPvWaves * 64);
+  const dim3 grid(tile_count(a.batch, 64)), block(kPvWaves * 64);
   if (a.x)
     k_forward_pv<P, true><<<grid, block, 0, s>>>(a);
   else
@@ -36,11 +36,11 @@ static void run_forward_pv(const FwdArgsP2& a, hipStream_t s) {
 }
 int launch_forward_pv(const ProblemDesc& p, const GridDesc& g, int batch, const double* x0, const double* u, double* x,
                       double* J, hipStream_t s, bool no_cost_row, const int* gate, const int* frozen) {
-  if (!vector_problem_ok(p) || g.N < 8 || g.N % 8 != 0 || batch < 64 || batch % 64 != 0) return -1;
+  if (!vector_problem_ok(p) || g.N < 8 || g.N % 8 != 0 || batch < 64 || !tile_ok(batch, 64)) return -1;
   const FwdArgsP2 a{g.N, batch, g.REC, p.ps, p.pb, p.pmask, x0, u, x, J, frozen, 0, no_cost_row ? 1 : 0, gate};
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
-    return jit_launch(p.user, x ? UK_FWD_PV_X : UK_FWD_PV_J, dim3(batch / 64), dim3(kPvWaves * 64), args, s);
+    return jit_launch(p.user, x ? UK_FWD_PV_X : UK_FWD_PV_J, dim3(tile_count(batch, 64)), dim3(kPvWaves * 64), args, s);
   }
   switch (p.nS) {
     case 1: run_forward_pv<LogisticK<1>>(a, s); break;

@@ -45,7 +45,7 @@ __global__ __launch_bounds__((PVCfg<P::NS, P::NC>::NWAVE * 64)) void k_forward_p
   const int lane = threadIdx.x & 63;
   const size_t B = (size_t)a.batch;
   const int nb = a.N / D;
-  const int bw = blockIdx.x * 64;
+  const int bw = tile_base(blockIdx.x, 64, a.batch);   // (a ragged last tile overlaps its neighbour, ocs_device_common.hpp)
   const int b0 = bw + lane;
   const bool valid = b0 < a.batch;
   const int b = valid ? b0 : a.batch - 1;
