@@ -207,7 +207,26 @@ int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* 
   }
   // The seven small tables in ONE device buffer that the calling thread keeps between calls (grow-only, per device): seven
   // hipMalloc / hipFree pairs per call were most of the call's 250-450 us at batch 4096.  One staged host array, one copy.
-  const size_t nd = (size_t)n * 5 + (size_t)nq * 2 + 8;   // doubles: TN n | HN n | W1 n | W2 n | IH n | SQ nq | KQ (ints) nq
+  // 'pchip': the query points sorted by interval (counting sort), so that a thread evaluates all points of its intervals from
+  // one set of node slopes (k_interp_pchip_sorted): QS [n] offsets per interval, QI [nq] original indices, SS [nq] coordinates
+  const bool sorted = method == OCS_INTERP_PCHIP;
+  std::vector<int> qs, qi;
+  std::vector<double> ss;
+  if (sorted) {
+    qs.assign((size_t)n, 0);
+    for (int j = 0; j < nq; ++j) ++qs[kq[j] + 1];
+    for (int k = 1; k < n; ++k) qs[k] += qs[k - 1];
+    qi.resize(nq);
+    ss.resize(nq);
+    std::vector<int> at(qs.begin(), qs.end() - 1);
+    for (int j = 0; j < nq; ++j) {
+      const int pos = at[kq[j]]++;
+      qi[pos] = j;
+      ss[pos] = sq[j];
+    }
+  }
+  const size_t nd = (size_t)n * 5 + (size_t)nq * 2 + 8 + (sorted ? (size_t)n + 2 * (size_t)nq + 8 : 0);
+  // doubles: TN n | HN n | W1 n | W2 n | IH n | SQ nq | KQ (ints) nq [| SS nq | QS (ints) n | QI (ints) nq]
   std::vector<double> stage(nd, 0.0);
   double* hp = stage.data();
   memcpy(hp, x, sizeof(double) * n);
@@ -217,6 +236,12 @@ int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* 
   memcpy(hp + 4 * (size_t)n, ih.data(), sizeof(double) * (n - 1));
   memcpy(hp + 5 * (size_t)n, sq.data(), sizeof(double) * nq);
   memcpy(hp + 5 * (size_t)n + nq, kq.data(), sizeof(int) * nq);
+  const size_t oSS = 5 * (size_t)n + 2 * (size_t)nq + 8, oQS = oSS + nq, oQI = oQS + (size_t)(n + 1) / 2 + 1;
+  if (sorted) {
+    memcpy(hp + oSS, ss.data(), sizeof(double) * nq);
+    memcpy(hp + oQS, qs.data(), sizeof(int) * n);
+    memcpy(hp + oQI, qi.data(), sizeof(int) * nq);
+  }
   struct Scratch {
     DevBuf buf;
     int device = -1;
@@ -234,7 +259,10 @@ int ocs_interp_dev(int method, int nComp, int n, const double* x, const double* 
   const FbsTables tb{n, dp, dp + n, dp + 2 * (size_t)n, dp + 3 * (size_t)n, nullptr, dp + 4 * (size_t)n, nullptr};
   // ('nearest' and 'next' pick a sample like 'previous' does: the kernel's sample-index mode)
   const int kmethod = (method == OCS_INTERP_NEAREST || method == OCS_INTERP_NEXT) ? OCS_INTERP_PREVIOUS : method;
-  LAUNCH_TRY(launch_interp(kmethod, tb, nComp, nq, (const int*)(dp + 5 * (size_t)n + nq), dp + 5 * (size_t)n, batch, v, out, s));
+  if (sorted)
+    LAUNCH_TRY(launch_interp_pchip_sorted(tb, nComp, (const int*)(dp + oQS), (const int*)(dp + oQI), dp + oSS, batch, v, out, s));
+  else
+    LAUNCH_TRY(launch_interp(kmethod, tb, nComp, nq, (const int*)(dp + 5 * (size_t)n + nq), dp + 5 * (size_t)n, batch, v, out, s));
   HIP_TRY(hipStreamSynchronize(s));   // (the staged host array lives until here)
   return OCS_OK;
 }

@@ -640,6 +640,55 @@ __global__ __launch_bounds__(256) void k_control_grid(const ControlGridArgs a) {
 // of the sweep); method 0 'linear', 2 'previous' (KQ = -1: before the first node -> NaN; SQ unused), 3 'pchip'.
 // One thread takes kInterpPts consecutive query points of one (component, instance) column.
 // ---------------------------------------------------------------------------------------
+// 'pchip' with the query points sorted by interval (host: QS[k] .. QS[k+1] are the positions, in the sorted order, of the points
+// of interval k; QI their indices in the caller's order; SS their local coordinates): a thread takes kInterpRun consecutive
+// intervals of one (component, instance) column, forms each node slope once from a register window (pchip_run_w's formulas:
+// reciprocal spacings) and evaluates every point of its intervals -- 2 loads per output at two points per interval where the
+// point-by-point kernel below makes 8 and divides 6 times.
+constexpr int kInterpRun = 4;
+__global__ __launch_bounds__(256) void k_interp_pchip_sorted(PchipTab T, int nComp, int batch, const int* __restrict__ QS,
+                                                             const int* __restrict__ QI, const double* __restrict__ SS,
+                                                             const double* __restrict__ V, double* __restrict__ out) {
+  constexpr int R = kInterpRun;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = blockIdx.z, n = T.n;
+  const int i0 = blockIdx.y * R;
+  if (b >= batch || i0 > n - 2) return;
+  const size_t B = (size_t)batch, ldB = (size_t)nComp * B;
+  const double* v = V + (size_t)c * B + b;
+  auto clampi = [&](int k, int hi) OCS_INLINE { return k < 0 ? 0 : (k > hi ? hi : k); };
+  double w[R + 4];
+#pragma unroll
+  for (int j = 0; j < R + 4; ++j) w[j] = v[(size_t)clampi(i0 - 2 + j, n - 1) * ldB];
+  double sec[R + 3], d[R + 1];
+#pragma unroll
+  for (int j = 0; j < R + 3; ++j) sec[j] = (w[j + 1] - w[j]) * T.IH[clampi(i0 - 2 + j, n - 2)];
+#pragma unroll
+  for (int cc = 0; cc <= R; ++cc) {
+    const int k = i0 + cc;
+    double dk;
+    if (n == 2) dk = sec[2];
+    else if (k == 0) dk = pchip_end(T.HN[0], T.HN[1], sec[cc + 2], sec[cc + 3]);
+    else if (k == n - 1) dk = pchip_end(T.HN[n - 2], T.HN[n - 3], sec[cc + 1], sec[cc]);
+    else if (k < n - 1) dk = pchip_interior1(sec[cc + 1], sec[cc + 2], T.W1[k], T.W2[k]);
+    else dk = 0.0;
+    d[cc] = dk;
+  }
+#pragma unroll
+  for (int cc = 0; cc < R; ++cc) {
+    const int k = i0 + cc;
+    if (k > n - 2) break;
+    const double ih = T.IH[k], del = sec[cc + 2];
+    const double dzzdx = (del - d[cc]) * ih, dzdxdx = (d[cc + 1] - del) * ih;
+    const double c3 = (dzdxdx - dzzdx) * ih, c2 = 2.0 * dzzdx - dzdxdx;
+    const int q1 = QS[k + 1];
+    for (int q = QS[k]; q < q1; ++q) {   // (wave-uniform trip count)
+      const double sq = SS[q];
+      out[((size_t)QI[q] * nComp + c) * B + b] = w[cc + 2] + sq * (d[cc] + sq * (c2 + sq * c3));
+    }
+  }
+}
+
 constexpr int kInterpPts = 4;
 __global__ __launch_bounds__(256) void k_interp(int method, PchipTab T, int nComp, int nq, int batch, const int* KQ,
                                                 const double* SQ, const double* V, double* out) {

@@ -149,6 +149,13 @@ int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* 
   return hip_rc3(hipGetLastError());
 }
 
+int launch_interp_pchip_sorted(const FbsTables& t, int nComp, const int* QS, const int* QI, const double* SS, int batch,
+                               const double* V, double* out, hipStream_t s) {
+  k_interp_pchip_sorted<<<dim3((batch + 255) / 256, (t.n - 1 + kInterpRun - 1) / kInterpRun, nComp), dim3(256), 0, s>>>(
+      make_tab(t), nComp, batch, QS, QI, SS, V, out);
+  return hip_rc3(hipGetLastError());
+}
+
 // start of a solve: usel = 0, status = 0, maxChange = NaN (all-ones) in one launch instead of three memsets
 __global__ void k_fbs_init(int batch, long long nmc, int* __restrict__ usel, int* __restrict__ status,
                            unsigned long long* __restrict__ mc) {

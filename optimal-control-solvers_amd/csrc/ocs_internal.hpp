@@ -271,6 +271,9 @@ int control_grid_parts(int N);
 // batched vectorInterpolant: V [n][nComp][B] -> out [nq][nComp][B]; method as OCS_INTERP_*; t: tables of the sample grid
 int launch_interp(int method, const FbsTables& t, int nComp, int nq, const int* KQ, const double* SQ, int batch,
                   const double* V, double* out, hipStream_t s);
+// 'pchip' with the query points sorted by interval (QS [n], QI [nq], SS [nq]: ocs_fbs_device.hpp k_interp_pchip_sorted)
+int launch_interp_pchip_sorted(const FbsTables& t, int nComp, const int* QS, const int* QI, const double* SS, int batch,
+                               const double* V, double* out, hipStream_t s);
 int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables& t, int batch, const double* x, int ldx,
                         const double* xmid, const double* lam, double* u, const int* status, double* metric,
                         double relTol, double absTol, hipStream_t s, int ldb = 0, const int* gate = nullptr,
