@@ -1,5 +1,5 @@
 import os, sys, numpy as np
-ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..')
+ROOT = os.path.join(os.path.dirname(os.path.abspath(__file__)), '..', '..')
 sys.path.insert(0, ROOT)
 import __graft_entry__ as g
 ocs = g.load_package()
