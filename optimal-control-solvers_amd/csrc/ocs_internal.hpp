@@ -1,6 +1,7 @@
 // ocs_internal.hpp -- launcher interface between the C-ABI layer (ocs_api.cpp) and the
 // gfx950 kernels (ocs_kernels.hip).  Not part of the public boundary.
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stddef.h>
 
@@ -76,6 +77,9 @@ int launch_build_recs(int N, int rs, int sco, const double* REC, double* RECS_ba
 bool pipeline_supported(Functor f, int nS, int nC);
 // tiles of `tile` trajectories: whole, or with a ragged last tile taken by a workgroup that overlaps its neighbour (tile_base,
 // ocs_device_common.hpp): more than one tile and an even batch
+// (odd batches were tried: with four states the overlapped instances of the sweep kernels then differ at 1e-8 between the two
+//  workgroups that compute them -- rows start at odd multiples of 8 bytes and the kernels pair trajectories in 16-byte accesses;
+//  one and two states were clean.  Even batches only.)
 inline bool tile_ok(int batch, int tile) { return batch % tile == 0 || (batch > tile && batch % 2 == 0); }
 inline int tile_count(int batch, int tile) { return (batch + tile - 1) / tile; }
 bool pipeline_shape_ok(int nS, int N, int batch, bool backward);  // nSTEPS multiple of the block, batch of the tile

@@ -1400,7 +1400,7 @@ bool pipeline_shape_ok(int nS, int N, int batch, bool backward) {
   if (N < D || N % D != 0) return false;
   // whole tiles; the state pass (k_forward_p2) also takes a ragged last tile as a workgroup that overlaps its neighbour, given
   // at least one tile and an even row distance (ocs_pipeline2_kernel.hpp)
-  return batch % TPW == 0 || (!backward && batch > TPW && batch % 2 == 0);
+  return batch % TPW == 0 || (!backward && tile_ok(batch, TPW));
 }
 int pipeline_block_steps() { return 8; }
 
