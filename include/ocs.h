@@ -315,7 +315,8 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double *x
  * fused into one kernel and sweeps enqueued one ahead; 3 windows of the batch on their own streams; 4 the two-kernel
  * sweep (state pass with the control update folded in + costate pass with the convergence test, csrc/ocs_fold_kernel.hpp):
  * registry problems of the logistic family and hipRTC problems created with flag bit 2 (row functions, ocs_ControlChar of
- * the costate alone). */
+ * the costate alone); 5 the sequence of 1 with the error points off the grid nodes (or a given u0), its kernels gated and
+ * enqueued ahead like 2. */
 int ocs_fb_sweep_path(ocs_integrator g);
 
 /* ---- the batch axis over the GPUs of one node (the reference has no batch axis and no parallelism:

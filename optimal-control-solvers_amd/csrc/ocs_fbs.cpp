@@ -20,6 +20,7 @@ struct ocs_fbs_state {
   bool err_on_nodes = false;  // the error points are the grid nodes (the default on a linspace tspan)
   int last_path = 0;          // ocs_fb_sweep_path
   DevBuf KE, SE, TE, TUE, KI, SI, TI, TUI;
+  DevBuf QSE;   // error points by interval: offsets [n] (they are sorted: linspace)
   unsigned long long tu_version = 0;
   const ocs_problem_s* tu_prob = nullptr;
   // windows of the batch on their own streams (fb_sweep with the fused control update)
@@ -35,6 +36,7 @@ struct ocs_fbs_state {
 
 void ocs_fbs_state_free(ocs_fbs_state* s) {
   if (!s) return;
+  s->QSE.release();
   DevBuf* bufs[] = {&s->TN, &s->HN, &s->W1, &s->W2, &s->TM, &s->IH, &s->PR, &s->KE, &s->SE, &s->TE, &s->TUE, &s->KI, &s->SI,
                     &s->TI, &s->TUI, &s->xaug, &s->xmid, &s->lam, &s->lmid, &s->ugrid, &s->uerr, &s->uint_, &s->J,
                     &s->usel, &s->status, &s->maxchange, &s->nactive, &s->x0, &s->stage, &s->metric, &s->anyvalid, &s->dump};
@@ -118,7 +120,8 @@ static FbsTables tabs(const ocs_integrator_s* g) {
 
 // interval index and local coordinate of query points linspace(T0, TF, nq)
 // *on_nodes (optional): the query points are exactly the grid nodes, in order
-static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBuf& T, bool* on_nodes = nullptr) {
+static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBuf& T, bool* on_nodes = nullptr,
+                        DevBuf* QS = nullptr) {
   const int n = g->N + 1;
   std::vector<double> q, tn(n), s(nq);
   std::vector<int> k(nq);
@@ -150,6 +153,12 @@ static int build_points(ocs_integrator_s* g, int nq, DevBuf& K, DevBuf& S, DevBu
     bool same = nq == n;
     for (int j = 0; same && j < n; ++j) same = std::fabs(q[j] - tn[j]) <= tol;
     *on_nodes = same;
+  }
+  if (QS) {   // offsets of the points of every interval (the points are in ascending order)
+    std::vector<int> qs((size_t)n, 0);
+    for (int j = 0; j < nq; ++j) ++qs[k[j] + 1];
+    for (int i = 1; i < n; ++i) qs[i] += qs[i - 1];
+    OCS_TRY(upload(*QS, qs.data(), sizeof(int) * n));
   }
   OCS_TRY(upload(K, k.data(), sizeof(int) * nq));
   OCS_TRY(upload(S, s.data(), sizeof(double) * nq));
@@ -449,7 +458,7 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const int ntu = std::max(1, functor_ntu(p->functor, p->nS));
   bool newpts = false;
   if (f->nerr != nE) {
-    OCS_TRY(build_points(g, nE, f->KE, f->SE, f->TE, &f->err_on_nodes));
+    OCS_TRY(build_points(g, nE, f->KE, f->SE, f->TE, &f->err_on_nodes, &f->QSE));
     f->nerr = nE;
     newpts = true;
   }
@@ -481,7 +490,10 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   const double om = opt->uRelax > 0.0 ? opt->uRelax : 1.0;
   const int fuo = opt->fused_update_off == 3 ? 0 : opt->fused_update_off;   // 3: as 0, without the fold below
   const bool fusedup = f->err_on_nodes && !u0grid && fuo != 1;
-  const int nparts = fusedup ? control_grid_parts(N) : control_pts_parts(nE);
+  // error points off the nodes: by runs of intervals where the sorted kernel applies (registry problems), else point by point
+  static const bool cps_off = getenv("OCS_CONTROL_PTS_SORTED") && getenv("OCS_CONTROL_PTS_SORTED")[0] == '0';
+  const bool cps = !fusedup && !cps_off && control_pts_sorted_ok(describe(p)) && f->QSE.p;
+  const int nparts = fusedup ? control_grid_parts(N) : (cps ? control_pts_run_parts(N) : control_pts_parts(nE));
   OCS_TRY(f->metric.ensure(sizeof(double) * (size_t)nparts * B));
   OCS_TRY(f->anyvalid.ensure(sizeof(int) * B));
   double* mc = maxChange;
@@ -610,10 +622,14 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
   // (every state pass of the sweep takes the gate -- the wave-specialised kernels, split passes, the lane kernel of any
   //  plugin -- so the loop is the same for every problem: what differs is whether the pchip midpoints of x are a kernel
   //  of their own)
-  if (fusedup && nwin == 1 && (fold || forward_gate_any(pd))) {
+  // ... and the same for error points OFF the grid nodes (the reference's default of 1001 points on any grid but N = 1000, a given
+  // u0): the kernels of the kernel-by-kernel sequence below, gated and enqueued ahead (path 5).  That sequence waited for the
+  // host once per sweep: 485 against ~250 us per sweep at 500 steps.
+  const bool ahead1 = !fusedup && fuo == 0 && opt->nWINDOWS <= 1 && forward_gate_any(pd);
+  if ((fusedup && nwin == 1 && (fold || forward_gate_any(pd))) || ahead1) {
     const int nsw = opt->nSWEEPS;
     const bool ownx = fuo == 0 && costate_forms_midpoints(pd, N, batch);   // midpoints inside the costate / control kernels
-    f->last_path = fold ? 4 : 2;
+    f->last_path = fold ? 4 : (fusedup ? 2 : 5);
     if (f->h_nact_cap < nsw) {
       if (f->h_nact) (void)hipHostFree(f->h_nact);
       f->h_nact = nullptr;
@@ -666,6 +682,23 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
       if (!ownx) LAUNCH_TRY(launch_pchip_mid(tb, nS, nAug, batch, xaug, f->xmid.d(), s, 0, gate));
       LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, xmid, f->ugrid.d(), status, f->dump.d(), lam, s, 0, tb.PR,
                                 gate));
+      if (!fusedup) {   // error points off the nodes: uNew there with check_convergence (:96, :99-115), then u = uNew on the grid
+        if (cps)
+          LAUNCH_TRY(launch_control_pts_sorted(pd, tb, nE, (const int*)f->QSE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
+                                               f->uerr.d(), f->metric.d(), opt->uRelTol, opt->uAbsTol, s, om, gate));
+        else
+          LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
+                                        f->uerr.d(), usel, (long long)uerrN, f->metric.d(), (int*)f->anyvalid.p, opt->uRelTol,
+                                        opt->uAbsTol, s, om, gate));
+        LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
+                                      mc, dslots + (sweep - 1), s, 0, gate));
+        // (only the instances that continue take uNew: status is the one k_fbs_advance just wrote, :85 / :82)
+        LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, xmid, lam, f->ugrid.d(), status, nullptr, 0.0, 0.0, s, 0,
+                                       gate, om));
+        HIP_TRY(hipMemcpyAsync(f->h_nact + (sweep - 1), dslots + (sweep - 1), sizeof(int), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipEventRecord(f->wevents[sweep % nev], s));
+        return OCS_OK;
+      }
       LAUNCH_TRY(launch_control_grid(pd, gd, tb, batch, xaug, nAug, xmid, lam, f->ugrid.d(), status, f->metric.d(),
                                      opt->uRelTol, opt->uAbsTol, s, 0, gate, om));
       LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p, (int*)f->usel.p, status,
@@ -713,9 +746,13 @@ int ocs_fb_sweep_dev(ocs_integrator g, ocs_problem p, int batch, const double* x
     LAUNCH_TRY(launch_costate(pd, gd, batch, xaug, nAug, f->xmid.d(), f->ugrid.d(), status, f->dump.d(), lam, s));
     // ... uNew = ControlChar(t, x(t), lam(t)) (:96) on the error points, with check_convergence(uNew, u)
     // (:81, :99-115) folded in
-    LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
-                                  f->uerr.d(), usel, (long long)uerrN, f->metric.d(),
-                                  (int*)f->anyvalid.p, opt->uRelTol, opt->uAbsTol, s, om));
+    if (cps)
+      LAUNCH_TRY(launch_control_pts_sorted(pd, tb, nE, (const int*)f->QSE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
+                                           f->uerr.d(), f->metric.d(), opt->uRelTol, opt->uAbsTol, s, om));
+    else
+      LAUNCH_TRY(launch_control_pts(pd, tb, nE, (const int*)f->KE.p, f->SE.d(), f->TUE.d(), batch, xaug, nAug, lam,
+                                    f->uerr.d(), usel, (long long)uerrN, f->metric.d(),
+                                    (int*)f->anyvalid.p, opt->uRelTol, opt->uAbsTol, s, om));
     LAUNCH_TRY(launch_fbs_advance(batch, sweep, nparts, f->metric.d(), (int*)f->anyvalid.p,
                                   (int*)f->usel.p, status, mc, (int*)f->nactive.p, s));
     // u = uNew (:85) on the integrator grid, only for the instances that continue: a converged instance

@@ -178,6 +178,26 @@ struct PchipSlide {
   __device__ static inline double next(const PchipTabU& T, const double* V, size_t ldB, int i) {
     return V[(size_t)cl(i + 3, T.n - 1) * ldB];
   }
+  // the cubic of interval i as v0 + s (d0 + s (c2 + s c3)), then the window moves to i + 1 (several points per interval)
+  __device__ inline void coef(const PchipTabU& T, const double* V, size_t ldB, int i, double vd, double& v0, double& d0, double& c2,
+                              double& c3) {
+    const int n = T.n, k = i + 1;
+    const double sn = (vc - vb) * T.IH[cl(i + 1, n - 2)];
+    double dn;
+    if (n == 2) dn = sc;
+    else if (k == n - 1) {
+      const double sp = (va - V[(size_t)cl(i - 1, n - 1) * ldB]) * T.IH[cl(i - 1, n - 2)];
+      dn = pchip_end(T.HN[n - 2], T.HN[n - 3], sc, sp);
+    } else dn = pchip_interior1(sc, sn, T.W1[k], T.W2[k]);
+    const double ih = T.IH[i], del = sc;
+    const double dzzdx = (del - di) * ih, dzdxdx = (dn - del) * ih;
+    c3 = (dzdxdx - dzzdx) * ih;
+    c2 = 2.0 * dzzdx - dzdxdx;
+    v0 = va;
+    d0 = di;
+    sc = sn;
+    va = vb; vb = vc; vc = vd; di = dn;
+  }
   __device__ inline double step(const PchipTabU& T, const double* V, size_t ldB, int i, double s, double vd) {   // i < n - 1
     const int n = T.n, k = i + 1;
     const double sn = (vc - vb) * T.IH[cl(i + 1, n - 2)];
@@ -744,6 +764,7 @@ struct ControlPtsArgs {
   int* anyvalid;   // unused (kept for the argument layout)
   double relTol, absTol;
   double relax;    // error-point mode: the samples become u + relax (uNew - u) (1: the reference's u = uNew, fb_sweep.m:85)
+  const int* gate = nullptr;   // optional: the launch does nothing if *gate == 0 (a sweep enqueued ahead of the verdict before it)
 };
 
 constexpr int kPtsPerThread = 8;
@@ -752,6 +773,7 @@ template <class P>
 __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU;
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.gate && *a.gate == 0) return;
   if (b >= a.batch) return;
   double wmax = 0.0;
   bool any = false;
@@ -853,6 +875,82 @@ __global__ __launch_bounds__(256) void k_control_pts(const ControlPtsArgs a) {
   for (int c = 0; c < NC; ++c) dst[((size_t)q * NC + c) * B + b] = u[c];
   }  // q
   // partial maxima go to memory (one coalesced store per block row) and are reduced by k_fbs_advance: no atomics
+  if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? wmax : -1.0;
+}
+
+// The error-point mode of k_control_pts for points SORTED by interval (fb_sweep's linspace points are): a thread takes
+// kCtlRun consecutive intervals of one instance, walks them with one sliding window per row (the cubic of an interval once, every
+// point of the interval from it) and accumulates the weighted change over its points.  QS[k] .. QS[k+1]: the points of interval k.
+// Two points per interval (the reference's 1001 points on 500 steps) cost the point-by-point kernel 8 loads and 6 divisions per
+// row and point: 200 us per sweep at batch 16384 against 30-80 for every other kernel of the sweep.
+constexpr int kCtlRun = 4;
+template <class P>
+__global__ __launch_bounds__(256) void k_control_pts_sorted(const ControlPtsArgs a, const int* __restrict__ QS) {
+  constexpr int NS = P::NS, NC = P::NC, NTU = P::NTU, R = kCtlRun;
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (a.gate && *a.gate == 0) return;
+  if (b >= a.batch) return;
+  const int n = a.T.n, i0 = blockIdx.y * R;
+  const size_t B = (size_t)a.batch;
+  double wmax = 0.0;
+  bool any = false;
+  if (i0 <= n - 2) {
+    const PchipTabU TU_(a.T);
+    const typename P::Par p = P::load(ParamSrc{as_uniform(a.ps), a.pb, a.pmask, B, b});
+    double lb[NC], ub[NC];
+#pragma unroll
+    for (int c = 0; c < NC; ++c) {
+      lb[c] = a.lb[c];
+      ub[c] = a.ub[c];
+    }
+    PchipSlide sl[NS], sx[NS];
+#pragma unroll
+    for (int k = 0; k < NS; ++k) {
+      sl[k].init(TU_, a.lam + (size_t)k * B + b, (size_t)NS * B, i0);
+      if (P::CC_READS_X) sx[k].init(TU_, a.x + (size_t)k * B + b, (size_t)a.ldx * B, i0);
+    }
+    const int iend = i0 + R < n - 1 ? i0 + R : n - 1;
+#pragma unroll 1
+    for (int i = i0; i < iend; ++i) {
+      double lv[NS], ld[NS], l2[NS], l3[NS], xv[NS], xd[NS], x2[NS], x3[NS];
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        const double* lp = a.lam + (size_t)k * B + b;
+        sl[k].coef(TU_, lp, (size_t)NS * B, i, PchipSlide::next(TU_, lp, (size_t)NS * B, i), lv[k], ld[k], l2[k], l3[k]);
+        if (P::CC_READS_X) {
+          const double* xp = a.x + (size_t)k * B + b;
+          sx[k].coef(TU_, xp, (size_t)a.ldx * B, i, PchipSlide::next(TU_, xp, (size_t)a.ldx * B, i), xv[k], xd[k], x2[k], x3[k]);
+        }
+      }
+      const int q1 = QS[i + 1];
+      for (int q = QS[i]; q < q1; ++q) {   // (wave-uniform)
+        const double sq = a.SQ[q];
+        double x[NS], lam[NS], tu[NTU], u[NC];
+#pragma unroll
+        for (int k = 0; k < NS; ++k) {
+          lam[k] = lv[k] + sq * (ld[k] + sq * (l2[k] + sq * l3[k]));
+          x[k] = P::CC_READS_X ? xv[k] + sq * (xd[k] + sq * (x2[k] + sq * x3[k])) : 0.0;
+        }
+#pragma unroll
+        for (int k = 0; k < NTU; ++k) tu[k] = as_uniform(a.TUQ)[(size_t)q * NTU + k];
+        P::control_char(tu, x, lam, p, lb, ub, u);
+#pragma unroll
+        for (int c = 0; c < NC; ++c) {
+          double* dst = a.out + ((size_t)q * NC + c) * B + b;
+          if (a.metric) {   // fb_sweep.m:107, as k_control_pts
+            const double o = *dst;
+            const double w = fabs(u[c] - o) / (a.relTol * fabs(o) + a.absTol);
+            if (w == w) {
+              wmax = any ? fmax(wmax, w) : w;
+              any = true;
+            }
+            if (a.relax != 1.0) u[c] = __builtin_fma(a.relax, u[c] - o, o);
+          }
+          *dst = u[c];
+        }
+      }
+    }
+  }
   if (a.metric) a.metric[(size_t)blockIdx.y * B + b] = any ? wmax : -1.0;
 }
 

@@ -114,9 +114,10 @@ static void run_control_pts(const ControlPtsArgs& a, hipStream_t s) {
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
                        const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
-                       double absTol, hipStream_t s, double relax) {
-  const ControlPtsArgs a{nq, batch, make_tab(t), KQ, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out,
-                         usel, odelta, metric, anyvalid, relTol, absTol, relax};
+                       double absTol, hipStream_t s, double relax, const int* gate) {
+  ControlPtsArgs a{nq, batch, make_tab(t), KQ, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out,
+                   usel, odelta, metric, anyvalid, relTol, absTol, relax};
+  a.gate = gate;
   if (p.functor == Functor::User) {
     void* args[] = {(void*)&a};
     return jit_launch(p.user, UK_CONTROL_PTS, dim3((batch + 255) / 256, (nq + kPtsPerThread - 1) / kPtsPerThread),
@@ -173,6 +174,23 @@ int launch_fbs_init(int batch, int nsweeps, int* usel, int* status, double* maxC
 }
 
 int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
+// the error-point mode on points sorted by interval (k_control_pts_sorted): registry problems
+int control_pts_run_parts(int N) { return (N + kCtlRun - 1) / kCtlRun; }
+bool control_pts_sorted_ok(const ProblemDesc& p) { return p.functor == Functor::Logistic && p.nS >= 1 && p.nS <= 4; }
+template <class P>
+static void run_control_pts_sorted(const ControlPtsArgs& a, const int* QS, hipStream_t s) {
+  k_control_pts_sorted<P><<<dim3((a.batch + 255) / 256, (a.T.n - 1 + kCtlRun - 1) / kCtlRun), dim3(256), 0, s>>>(a, QS);
+}
+int launch_control_pts_sorted(const ProblemDesc& p, const FbsTables& t, int nq, const int* QS, const double* SQ,
+                              const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
+                              double* metric, double relTol, double absTol, hipStream_t s, double relax, const int* gate) {
+  if (!control_pts_sorted_ok(p)) return -1;
+  ControlPtsArgs a{nq, batch, make_tab(t), nullptr, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out,
+                   nullptr, 0, metric, nullptr, relTol, absTol, relax};
+  a.gate = gate;
+  OCS_DISPATCH_LOGISTIC2(p.nS, run_control_pts_sorted<P>(a, QS, s));
+  return hip_rc3(hipGetLastError());
+}
 int launch_fbs_advance(int batch, int sweep, int nparts, const double* metric, int* anyvalid, int* usel, int* status,
                        double* maxChange, int* nactive, hipStream_t s, int ldb, const int* gate) {
   k_fbs_advance<<<dim3((batch + 63) / 64), dim3(64), 0, s>>>(batch, sweep, nparts, metric, anyvalid, usel, status,

@@ -285,7 +285,14 @@ int launch_control_grid(const ProblemDesc& p, const GridDesc& g, const FbsTables
 int launch_control_pts(const ProblemDesc& p, const FbsTables& t, int nq, const int* KQ, const double* SQ,
                        const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
                        const int* usel, long long odelta, double* metric, int* anyvalid, double relTol,
-                       double absTol, hipStream_t s, double relax = 1.0);
+                       double absTol, hipStream_t s, double relax = 1.0, const int* gate = nullptr);
+// error-point mode on points sorted by interval (QS [n]: offsets per interval): registry problems; parts = control_pts_run_parts(N)
+int control_pts_run_parts(int N);
+bool control_pts_sorted_ok(const ProblemDesc& p);
+int launch_control_pts_sorted(const ProblemDesc& p, const FbsTables& t, int nq, const int* QS, const double* SQ,
+                              const double* TUQ, int batch, const double* x, int ldx, const double* lam, double* out,
+                              double* metric, double relTol, double absTol, hipStream_t s, double relax = 1.0,
+                              const int* gate = nullptr);
 int launch_tu_at(const ProblemDesc& p, int nq, const double* tq, double* TUQ, hipStream_t s);
 int control_pts_parts(int nq);  // rows of the partial-maximum array `metric` [parts][B] that launch_control_pts fills
 int launch_fbs_init(int batch, int nsweeps, int* usel, int* status, double* maxChange, hipStream_t s);
