@@ -176,7 +176,9 @@ int launch_fbs_init(int batch, int nsweeps, int* usel, int* status, double* maxC
 int control_pts_parts(int nq) { return (nq + kPtsPerThread - 1) / kPtsPerThread; }
 // the error-point mode on points sorted by interval (k_control_pts_sorted): registry problems
 int control_pts_run_parts(int N) { return (N + kCtlRun - 1) / kCtlRun; }
-bool control_pts_sorted_ok(const ProblemDesc& p) { return p.functor == Functor::Logistic && p.nS >= 1 && p.nS <= 4; }
+bool control_pts_sorted_ok(const ProblemDesc& p) {
+  return (p.functor == Functor::Logistic || p.functor == Functor::User) && p.nS >= 1 && p.nS <= 4;
+}
 template <class P>
 static void run_control_pts_sorted(const ControlPtsArgs& a, const int* QS, hipStream_t s) {
   k_control_pts_sorted<P><<<dim3((a.batch + 255) / 256, (a.T.n - 1 + kCtlRun - 1) / kCtlRun), dim3(256), 0, s>>>(a, QS);
@@ -188,6 +190,10 @@ int launch_control_pts_sorted(const ProblemDesc& p, const FbsTables& t, int nq, 
   ControlPtsArgs a{nq, batch, make_tab(t), nullptr, SQ, TUQ, p.ps, p.pb, p.pmask, p.lb, p.ub, x, ldx, lam, out,
                    nullptr, 0, metric, nullptr, relTol, absTol, relax};
   a.gate = gate;
+  if (p.functor == Functor::User) {
+    void* args[] = {(void*)&a, (void*)&QS};
+    return jit_launch(p.user, UK_CONTROL_PTS_SORTED, dim3((batch + 255) / 256, (t.n - 1 + kCtlRun - 1) / kCtlRun), dim3(256), args, s);
+  }
   OCS_DISPATCH_LOGISTIC2(p.nS, run_control_pts_sorted<P>(a, QS, s));
   return hip_rc3(hipGetLastError());
 }

@@ -88,6 +88,7 @@ static std::vector<std::string> kernel_names(int nS, int nC, bool rowsep, bool f
   n[UK_COSTATE] = "ocs::k_costate<ocs::UserP, 4>";
   n[UK_CONTROL_GRID] = "ocs::k_control_grid<ocs::UserP, false>";
   n[UK_CONTROL_PTS] = "ocs::k_control_pts<ocs::UserP>";
+  if (nS <= 4) n[UK_CONTROL_PTS_SORTED] = "ocs::k_control_pts_sorted<ocs::UserP>";
   n[UK_TU_AT] = "ocs::k_tu_at<ocs::UserP>";
   n[UK_EQUILIBRIUM] = "ocs::k_equilibrium<ocs::UserP>";
   const std::string wl = std::to_string(kScanW) + ", " + std::to_string(kScanL);

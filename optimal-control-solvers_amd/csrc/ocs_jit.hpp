@@ -34,6 +34,8 @@ enum UserKernel : int {
   UK_COSTATE_VSCAN,
   // nS <= 4: the lane adjoint kernel with checkpoint re-integration and non-temporal stores (HBM-bound launches, full output)
   UK_BWD_LAM_DJDU_XRC,
+  // nS <= 4 with ocs_ControlChar: the error-point mode of fb_sweep by runs of intervals (k_control_pts_sorted)
+  UK_CONTROL_PTS_SORTED,
   UK_COUNT
 };
 
