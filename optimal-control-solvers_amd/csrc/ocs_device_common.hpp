@@ -23,6 +23,9 @@ __device__ static inline void chain_wave_priority() {
 // instance twice, they are only compared with zero).  Launchers ask for it with batch > TPW and an even batch (16-byte DMA chunks).
 __device__ static inline int tile_base(int block, int TPW, int batch) {
   const int b0 = block * TPW;
+#ifdef OCS_NO_TILE_OVERLAP   // (A/B builds)
+  return b0;
+#endif
   return b0 + TPW <= batch ? b0 : batch - TPW;
 }
 
